@@ -1,0 +1,174 @@
+/*
+ * unetrir.h - C ABI of the MI355X (gfx950) U-Net train-step hot path.
+ *
+ * The reference (igmsalinas/unet-rir) has no FFI: its hot path is a Keras graph
+ * (dl_models/u_net.py:201-251) that TensorFlow lowers to cuDNN / NCCL.  Each
+ * entry point below replaces the kernel TensorFlow would dispatch for one Keras
+ * call site; the call site is cited next to it.  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - device pointers only, caller owns every buffer, 16-byte aligned;
+ *   - activations are NHWC fp32 (the reference's own layout) addressed as
+ *     base + pixel * ld + channel, `ld` (pixel stride in elements) >= channels and a
+ *     multiple of 4, so a channel-concat is two writers into one buffer (no copy);
+ *   - Conv2D weights are [Cout][kh][kw][Cin] ("OHWI"), Conv2DTranspose weights
+ *     are [Cin][kh][kw][Cout] ("IHWO"): the layout the weight-gradient kernel
+ *     produces; unetrir_transpose_weight_f32 makes the other one;
+ *   - Cin and Cout multiples of 4 unless stated; TF padding='same' geometry;
+ *   - asynchronous on `stream`, never allocate, never synchronise, no global
+ *     mutable state (thread-safe for distinct streams);
+ *   - return 0 on success, a hipError_t value or UNETRIR_EINVAL otherwise.
+ */
+#ifndef UNETRIR_H
+#define UNETRIR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNETRIR_EINVAL 10001
+#define UNETRIR_ABI_VERSION 1
+
+typedef void* unetrir_stream_t; /* hipStream_t */
+
+/* Geometry of one Conv2D / Conv2DTranspose(padding='same') call.
+ * H, W: spatial size of the layer INPUT (for the transpose: the low-res input). */
+typedef struct {
+    int B, H, W;
+    int Cin, Cout;
+    int k;      /* square kernel size: 1, 3 or 6 in the reference graph */
+    int stride; /* 1 or 2 */
+} unetrir_conv_geom;
+
+int unetrir_abi_version(void);
+
+/* ---- Conv2D(padding='same'): dl_models/u_net.py:269-276 (strided, stride 1|2),
+ *      :366 (3x3 block conv), :248 (6x6 head), :262 (1x1 on the information vector).
+ *      y = conv(x, w) + bias (+ addend): `addend` (nullable) is the Add() of
+ *      dl_models/u_net.py:229 fused into the epilogue.                            */
+int unetrir_conv2d_fwd_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* w,
+                           const float* bias, const float* addend, int ldadd, float* y, int ldy,
+                           unetrir_stream_t stream);
+/* dL/dx of the above (TensorFlow: Conv2DBackpropInput via tape.gradient, main_training.py:267).
+ * wt = weights transposed to [Cin][kh][kw][Cout]; dx = conv^T(dy) (+ addend). */
+int unetrir_conv2d_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy, const float* wt,
+                             const float* addend, int ldadd, float* dx, int lddx,
+                             unetrir_stream_t stream);
+/* dL/dw (Conv2DBackpropFilter): dw[Cout][k][k][Cin] = sum_pixels dy * x  + reg_coef * w.
+ * Deterministic split-K: partials go to `ws` (>= unetrir_conv2d_wgrad_ws_bytes), then a
+ * fixed-order reduction.  `w` may be NULL when reg_coef == 0. */
+size_t unetrir_conv2d_wgrad_ws_bytes(const unetrir_conv_geom* g);
+int unetrir_conv2d_wgrad_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy,
+                             int lddy, float* dw, float reg_coef, const float* w, void* ws,
+                             size_t ws_bytes, unetrir_stream_t stream);
+
+/* ---- Conv2DTranspose(strides=2, padding='same'): dl_models/u_net.py:297-304.
+ *      Defined as the adjoint of the SAME stride-2 conv on the 2H x 2W grid.
+ *      fwd takes wt = [Cout][k][k][Cin]; dgrad and wgrad take/produce the primary
+ *      [Cin][k][k][Cout].  g->H, g->W are the low-res input size, g->stride = 2. */
+int unetrir_conv2d_transpose_fwd_f32(const unetrir_conv_geom* g, const float* x, int ldx,
+                                     const float* wt, const float* bias, float* y, int ldy,
+                                     unetrir_stream_t stream);
+int unetrir_conv2d_transpose_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy,
+                                       const float* w, const float* addend, int ldadd, float* dx,
+                                       int lddx, unetrir_stream_t stream);
+size_t unetrir_conv2d_transpose_wgrad_ws_bytes(const unetrir_conv_geom* g);
+int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* x, int ldx,
+                                       const float* dy, int lddy, float* dw, float reg_coef,
+                                       const float* w, void* ws, size_t ws_bytes,
+                                       unetrir_stream_t stream);
+
+/* [N][T][C] -> [C][T][N] (swap the channel roles of a conv kernel, taps kept). */
+int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C,
+                                 unetrir_stream_t stream);
+
+/* ---- BatchNormalization() training mode + Activation('relu'):
+ *      dl_models/u_net.py:367-369 (Keras defaults eps=1e-3, momentum=0.99).
+ *      x is [P][C] with pixel stride ldx.  stats: per-channel batch mean / biased
+ *      variance (fp64 accumulation, two-stage deterministic), writes
+ *      scale = gamma*rsqrt(var+eps), shift = beta - mean*scale into `affine[2*C]`,
+ *      mean and rstd into `saved[2*C]`, and updates the moving statistics
+ *      (moving = momentum*moving + (1-momentum)*batch, unbiased variance) when non-NULL.
+ *      ws >= unetrir_bn_ws_bytes(P, C). */
+size_t unetrir_bn_ws_bytes(long long P, int C);
+int unetrir_bn_stats_f32(const float* x, int ldx, long long P, int C, const float* gamma,
+                         const float* beta, float eps, float momentum, float* moving_mean,
+                         float* moving_var, float* affine, float* saved, void* ws, size_t ws_bytes,
+                         unetrir_stream_t stream);
+/* y = max(x*scale + shift, 0) (relu != 0) or x*scale + shift */
+int unetrir_bn_apply_f32(const float* x, int ldx, long long P, int C, const float* affine, int relu,
+                         float* y, int ldy, unetrir_stream_t stream);
+/* Backward of BN(+ReLU): given da = dL/d(output), the saved conv output x and the batch
+ * statistics, writes dx = dL/dx and dgamma, dbeta.  (TensorFlow: FusedBatchNormGradV3 + ReluGrad.) */
+int unetrir_bn_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C,
+                       const float* gamma, const float* affine, const float* saved, int relu,
+                       float* dx, int lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                       unetrir_stream_t stream);
+/* Per-channel column sum (BiasAddGrad): out[c] = sum_p x[p][c]. */
+int unetrir_colsum_f32(const float* x, int ldx, long long P, int C, float* out, void* ws,
+                       size_t ws_bytes, unetrir_stream_t stream);
+/* ReLU without BN (BatchNorm=False graphs): y = max(x, 0); dx = da * (x > 0). */
+int unetrir_relu_fwd_f32(const float* x, int ldx, long long P, int C, float* y, int ldy,
+                         unetrir_stream_t stream);
+int unetrir_relu_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C,
+                         float* dx, int lddx, unetrir_stream_t stream);
+
+/* ---- boundary layout: the model input is NCHW [B,2,H,W] (north_star); the first conv reads
+ *      NHWC padded to 4 channels.  nchw -> [B,H,W,Cpad] with zero fill, and back. */
+int unetrir_nchw_to_nhwc_pad_f32(const float* x, int B, int C, int H, int W, float* y, int Cpad,
+                                 unetrir_stream_t stream);
+
+/* ---- head: Activation('sigmoid') (dl_models/u_net.py:249) fused with the loss of
+ *      main_training.py:184-235.  logits is NHWC [B*H*W][ldl>=2]; pred/target are NCHW
+ *      [B,2,H,W].  Writes pred = sigmoid(logits); partial sums of the data loss into ws and
+ *      the final scalar loss_out[0] = sum(alpha*(a-a^)^2 + (1-alpha)*(1-cos(2pi(p-p^)))) /
+ *      (2*H*W*global_batch), loss_out[1] = sum of the amplitude term, loss_out[2] = sum of
+ *      the phase term; dlogits [B*H*W][4] = dL/dlogits (channels 2,3 zero). */
+size_t unetrir_loss_ws_bytes(long long npix);
+int unetrir_sigmoid_loss_f32(const float* logits, int ldl, const float* target, int B, int H, int W,
+                             float alpha, float inv_norm, float* pred, float* dlogits,
+                             float* loss_out, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* sigmoid only (inference / forward without a target) */
+int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, float* pred,
+                             unetrir_stream_t stream);
+/* dlogits from an upstream gradient on the NCHW prediction: dl = dpred * p * (1 - p) */
+int unetrir_sigmoid_bwd_f32(const float* pred, const float* dpred, int B, int H, int W,
+                            float* dlogits, unetrir_stream_t stream);
+
+/* ---- information vector branch: Embedding(2000,256) -> Flatten (dl_models/u_net.py:257-258).
+ *      idx int32 [n_idx]; out [n_idx][dim].  Backward is a deterministic gather-by-row:
+ *      dtable[v] = sum over positions with idx == v, in position order. */
+int unetrir_embedding_fwd_f32(const int* idx, int n_idx, const float* table, int vocab, int dim,
+                              float* out, unetrir_stream_t stream);
+int unetrir_embedding_bwd_f32(const int* idx, int n_idx, const float* dout, int vocab, int dim,
+                              float* dtable, unetrir_stream_t stream);
+/* y = x * mask (Dropout(.3), dl_models/u_net.py:260; mask already scaled by 1/(1-p)) */
+int unetrir_mul_f32(const float* x, const float* m, float* y, long long n, unetrir_stream_t stream);
+/* sum_i x_i^2 over n elements into out[0] (+= when accumulate != 0): l2 regulariser value. */
+int unetrir_sumsq_f32(const float* x, long long n, float coef, float* out, int accumulate,
+                      void* ws, size_t ws_bytes, unetrir_stream_t stream);
+
+/* ---- tf.keras.optimizers.Adam (main_training.py:168-169, :268): beta1 .9, beta2 .999,
+ *      epsilon 1e-7 outside the sqrt, lr_t = lr*sqrt(1-b2^t)/(1-b1^t).  One launch over a flat
+ *      parameter buffer.  grad_scale multiplies g first (1/world_size style rescaling). */
+int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long n, float lr_t,
+                     float beta1, float beta2, float eps, float grad_scale,
+                     unetrir_stream_t stream);
+
+/* ---- profiling hooks used by bench.py: when enabled every conv launch is bracketed by HIP
+ *      events on its own stream; collect() synchronises those events and returns, per kernel
+ *      family, launch count, total milliseconds and total algorithmic FLOPs. */
+#define UNETRIR_PROF_FAMILIES 8
+enum { UNETRIR_FAM_CONV_FWD = 0, UNETRIR_FAM_CONV_DGRAD = 1, UNETRIR_FAM_CONV_WGRAD = 2,
+       UNETRIR_FAM_BN = 3, UNETRIR_FAM_OTHER = 4 };
+int unetrir_prof_enable(int on);
+int unetrir_prof_collect(int* counts, double* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETRIR_H */

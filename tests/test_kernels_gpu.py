@@ -1,0 +1,267 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle on seeded inputs.
+fp32 tolerances are stated per test; the oracle side runs in fp64."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detrand, torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def U():
+    import unet_rir_amd
+    unet_rir_amd._lib.lib()
+    return unet_rir_amd
+
+
+DEV = "cuda:0"
+
+
+def close(actual, expected, tol, what=""):
+    a = actual.detach().double().cpu()
+    e = expected.detach().double().cpu()
+    assert a.shape == e.shape, (what, a.shape, e.shape)
+    scale = float(e.abs().max()) + 1e-30
+    err = float((a - e).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def to_nhwc_buf(x_nchw, ld, c0, dev):
+    """Embed an NCHW tensor into channels [c0, c0+C) of a poisoned [B,H,W,ld] device buffer."""
+    B, C, H, W = x_nchw.shape
+    buf = torch.full((B, H, W, ld), 777.0, dtype=torch.float32)
+    buf[..., c0:c0 + C] = x_nchw.permute(0, 2, 3, 1).float()
+    return buf.to(dev)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s
+    (2, 16, 24, 8, 16, 3, 1),
+    (2, 16, 24, 16, 32, 3, 2),
+    (1, 9, 7, 8, 8, 3, 2),         # odd input: SAME pads (1,1)
+    (2, 8, 8, 64, 128, 3, 1),      # BN=128 tile
+    (1, 10, 12, 40, 72, 3, 1),     # channels not multiples of 32
+    (1, 12, 12, 16, 8, 6, 1),      # head geometry: pads (2,3)
+    (1, 12, 12, 8, 8, 6, 2),
+    (2, 4, 4, 16, 64, 1, 1),       # 1x1 (information-vector conv)
+    (1, 20, 20, 4, 16, 3, 1),      # padded stem (Cin=4)
+    (1, 20, 20, 32, 4, 6, 1),      # padded head (Cout=4)
+    (3, 1, 1, 256, 64, 1, 1),      # Dense as a 1x1 conv on a 1x1 grid
+]
+
+
+def conv_data(case, dtype=torch.float64):
+    B, H, W, Ci, Co, k, s = case
+    x = torch.tensor(detrand.uniform(f"x{case}", (B, Ci, H, W), -1, 1, np.float64), dtype=dtype)
+    w = torch.tensor(detrand.uniform(f"w{case}", (k, k, Ci, Co), -1, 1, np.float64), dtype=dtype)
+    b = torch.tensor(detrand.uniform(f"b{case}", (Co,), -1, 1, np.float64), dtype=dtype)
+    return x, w, b
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(U, case):
+    ops = U.ops
+    B, H, W, Ci, Co, k, s = case
+    x, w, b = conv_data(case)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = R.conv2d_same(x, w, b, s)
+    Ho, Wo = y.shape[2], y.shape[3]
+    add = torch.tensor(detrand.uniform(f"a{case}", (B, Co, Ho, Wo), -1, 1, np.float64))
+    gy = torch.tensor(detrand.uniform(f"g{case}", (B, Co, Ho, Wo), -1, 1, np.float64))
+    (y * gy).sum().backward()
+    K = max(Ci * k * k, 1)
+    tol = 2e-6 * math.sqrt(K) + 1e-6
+
+    g = ops.geom(B, H, W, Ci, Co, k, s)
+    xa = ops.Act(to_nhwc_buf(x.detach(), Ci + 8, 4, DEV), 4, Ci)          # offset view: concat-style input
+    w_ohwi = w.detach().permute(3, 0, 1, 2).contiguous().float().to(DEV)
+    bias = b.float().to(DEV)
+    ya = ops.Act(torch.full((B, Ho, Wo, Co + 4), 555.0, device=DEV), 0, Co)
+    adda = ops.Act(to_nhwc_buf(add, Co, 0, DEV))
+    ops.conv2d_fwd(g, xa, w_ohwi, bias, ya, adda)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y.detach() + add, tol, "fwd")
+    assert float(ya.base[..., Co:].min()) == 555.0      # pad channels untouched
+
+    # dgrad
+    wt = torch.empty((Ci, k * k, Co), device=DEV)
+    ops.transpose_weight(w_ohwi, wt, Co, k * k, Ci)
+    torch.cuda.synchronize()
+    close(wt, w.detach().permute(2, 0, 1, 3).reshape(Ci, k * k, Co), 1e-7, "transpose_weight")
+    gya = ops.Act(to_nhwc_buf(gy, Co, 0, DEV))
+    dxa = ops.Act(torch.full((B, H, W, Ci), 333.0, device=DEV))
+    ops.conv2d_dgrad(g, gya, wt, dxa)
+    torch.cuda.synchronize()
+    close(dxa.dense().permute(0, 3, 1, 2), x.grad, 2e-6 * math.sqrt(Co * k * k) + 1e-6, "dgrad")
+
+    # wgrad (+ l2 regulariser gradient 2*coef*w folded into the reduction)
+    ws = ops.Workspace(DEV)
+    dw = torch.full((Co, k, k, Ci), 111.0, device=DEV)
+    reg = 0.002
+    ops.conv2d_wgrad(g, xa, gya, dw, ws, reg=reg, w=w_ohwi)
+    torch.cuda.synchronize()
+    exp = (w.grad + reg * w.detach()).permute(3, 0, 1, 2)
+    close(dw, exp, 2e-6 * math.sqrt(B * Ho * Wo) + 1e-6, "wgrad")
+
+
+CONVT_CASES = [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (1, 5, 6, 8, 16, 6), (2, 3, 3, 128, 64, 3)]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv2d_transpose(U, case):
+    ops = U.ops
+    B, H, W, Ci, Co, k = case
+    x = torch.tensor(detrand.uniform(f"tx{case}", (B, Ci, H, W), -1, 1, np.float64), requires_grad=True)
+    w = torch.tensor(detrand.uniform(f"tw{case}", (k, k, Co, Ci), -1, 1, np.float64), requires_grad=True)  # HWOI
+    b = torch.tensor(detrand.uniform(f"tb{case}", (Co,), -1, 1, np.float64))
+    y = R.conv2d_transpose_same(x, w, b, 2)
+    gy = torch.tensor(detrand.uniform(f"tg{case}", tuple(y.shape), -1, 1, np.float64))
+    (y * gy).sum().backward()
+
+    g = ops.geom(B, H, W, Ci, Co, k, 2)
+    w_prim = w.detach().permute(3, 0, 1, 2).contiguous().float().to(DEV)       # [Ci][kh][kw][Co]
+    wt = torch.empty((Co, k * k, Ci), device=DEV)
+    ops.transpose_weight(w_prim, wt, Ci, k * k, Co)
+    xa = ops.Act(to_nhwc_buf(x.detach(), Ci, 0, DEV))
+    ya = ops.Act(torch.full((B, 2 * H, 2 * W, 2 * Co), 555.0, device=DEV), Co, Co)   # upper half of a concat buffer
+    ops.conv2d_transpose_fwd(g, xa, wt, b.float().to(DEV), ya)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y.detach(), 2e-6 * math.sqrt(Ci * k * k) + 1e-6, "convT fwd")
+    assert float(ya.base[..., :Co].min()) == 555.0
+
+    gya = ops.Act(to_nhwc_buf(gy, 2 * Co, Co, DEV), Co, Co)
+    dxa = ops.Act(torch.full((B, H, W, Ci), 333.0, device=DEV))
+    ops.conv2d_transpose_dgrad(g, gya, w_prim, dxa)
+    torch.cuda.synchronize()
+    close(dxa.dense().permute(0, 3, 1, 2), x.grad, 2e-6 * math.sqrt(Co * k * k) + 1e-6, "convT dgrad")
+
+    ws = ops.Workspace(DEV)
+    dw = torch.full((Ci, k, k, Co), 111.0, device=DEV)
+    ops.conv2d_transpose_wgrad(g, xa, gya, dw, ws, reg=0.002, w=w_prim)
+    torch.cuda.synchronize()
+    close(dw, (w.grad + 0.002 * w.detach()).permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "convT wgrad")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 10, 16), (3, 7, 5, 40), (1, 4, 4, 1024), (2, 33, 31, 8)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_fwd_bwd(U, shape, relu):
+    ops = U.ops
+    B, H, W, Cc = shape
+    x = torch.tensor(detrand.uniform(f"bx{shape}", (B, Cc, H, W), -2, 2, np.float64), requires_grad=True)
+    gamma = torch.tensor(detrand.uniform(f"bg{shape}", (Cc,), 0.5, 1.5, np.float64), requires_grad=True)
+    beta = torch.tensor(detrand.uniform(f"bb{shape}", (Cc,), -0.5, 0.5, np.float64), requires_grad=True)
+    state = {"bn.moving_mean": torch.zeros(Cc, dtype=torch.float64), "bn.moving_variance": torch.ones(Cc, dtype=torch.float64)}
+    y = R.bn_relu(x, gamma, beta, state, "bn", True, relu=relu)
+    gy = torch.tensor(detrand.uniform(f"bgy{shape}", (B, Cc, H, W), -1, 1, np.float64))
+    (y * gy).sum().backward()
+
+    ws = ops.Workspace(DEV)
+    xa = ops.Act(to_nhwc_buf(x.detach(), Cc + 4, 4, DEV), 4, Cc)
+    aff = torch.empty(2 * Cc, device=DEV); saved = torch.empty(2 * Cc, device=DEV)
+    mm = torch.zeros(Cc, device=DEV); mv = torch.ones(Cc, device=DEV)
+    g32, b32 = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    ops.bn_stats(xa, g32, b32, aff, saved, ws, mm, mv)
+    ya = ops.Act(torch.empty((B, H, W, Cc), device=DEV))
+    ops.bn_apply(xa, aff, ya, relu=relu)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y.detach(), 2e-6, "bn fwd")
+    close(mm, state["bn.moving_mean"], 1e-5, "moving mean")
+    close(mv, state["bn.moving_variance"], 1e-5, "moving var")
+
+    gya = ops.Act(to_nhwc_buf(gy, Cc, 0, DEV))
+    dxa = ops.Act(torch.empty((B, H, W, Cc), device=DEV))
+    dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
+    ops.bn_bwd(gya, xa, g32, aff, saved, dxa, dg, db, ws, relu=relu)
+    torch.cuda.synchronize()
+    close(dxa.dense().permute(0, 3, 1, 2), x.grad, 1e-5, "bn dx")
+    close(dg, gamma.grad, 1e-5, "dgamma")
+    close(db, beta.grad, 1e-5, "dbeta")
+
+    cs = torch.empty(Cc, device=DEV)
+    ops.colsum(gya, cs, ws)
+    torch.cuda.synchronize()
+    close(cs, gy.sum(dim=(0, 2, 3)), 1e-5, "colsum")
+
+
+def test_relu_only(U):
+    ops = U.ops
+    x = torch.tensor(detrand.uniform("rx", (2, 5, 6, 8), -1, 1))
+    g = torch.tensor(detrand.uniform("rg", (2, 5, 6, 8), -1, 1))
+    xa, ga = ops.Act(x.to(DEV)), ops.Act(g.to(DEV))
+    ya, dxa = ops.Act(torch.empty_like(xa.base)), ops.Act(torch.empty_like(xa.base))
+    ops.relu_fwd(xa, ya); ops.relu_bwd(ga, xa, dxa)
+    torch.cuda.synchronize()
+    assert torch.equal(ya.base.cpu(), x.clamp_min(0))
+    assert torch.equal(dxa.base.cpu(), g * (x > 0))
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 20), (1, 33, 17)])
+def test_sigmoid_loss(U, shape):
+    ops = U.ops
+    B, H, W = shape
+    logits = torch.tensor(detrand.uniform(f"sl{shape}", (B, 2, H, W), -3, 3, np.float64), requires_grad=True)
+    target = torch.tensor(detrand.uniform(f"st{shape}", (B, 2, H, W), 0, 1, np.float64))
+    pred = torch.sigmoid(logits)
+    gb = 4 * B
+    loss = R.data_loss(target, pred, 0.9, gb)
+    loss.backward()
+    la = ops.Act(to_nhwc_buf(logits.detach(), 4, 0, DEV), 0, 4)
+    pr = torch.empty((B, 2, H, W), device=DEV)
+    dl = ops.Act(torch.empty((B, H, W, 4), device=DEV))
+    out = torch.zeros(4, device=DEV)
+    ws = ops.Workspace(DEV)
+    ops.sigmoid_loss(la, target.float().to(DEV), 0.9, 1.0 / (2 * H * W * gb), pr, dl, out, ws)
+    torch.cuda.synchronize()
+    close(pr, pred.detach(), 1e-6, "pred")
+    assert abs(float(out[0]) - float(loss.detach())) <= 2e-6 * abs(float(loss.detach()))
+    close(dl.dense()[..., :2].permute(0, 3, 1, 2), logits.grad, 2e-5, "dlogits")
+    assert float(dl.dense()[..., 2:].abs().max()) == 0.0
+    pr2 = torch.empty_like(pr)
+    ops.sigmoid_nchw(la, pr2)
+    torch.cuda.synchronize()
+    assert torch.equal(pr, pr2)
+
+
+def test_embedding_adam_misc(U):
+    ops = U.ops
+    idx = torch.tensor(detrand.randint("ei", (3, 2, 16), 26, 60), dtype=torch.int32)      # many duplicates
+    table = torch.tensor(detrand.uniform("et", (2000, 256), -0.05, 0.05))
+    out = torch.empty((idx.numel(), 256), device=DEV)
+    ops.embedding_fwd(idx.to(DEV), table.to(DEV), out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), table[idx.long().flatten()])
+    dout = torch.tensor(detrand.uniform("ed", (idx.numel(), 256), -1, 1))
+    dt = torch.full((2000, 256), 9.0, device=DEV)
+    ops.embedding_bwd(idx.to(DEV), dout.to(DEV), dt)
+    torch.cuda.synchronize()
+    exp = torch.zeros(2000, 256, dtype=torch.float64).index_add_(0, idx.long().flatten(), dout.double())
+    close(dt, exp, 1e-6, "embedding bwd")
+
+    n = 10007
+    th = torch.tensor(detrand.uniform("ath", (n,), -1, 1)); g = torch.tensor(detrand.uniform("ag", (n,), -1, 1))
+    m = torch.tensor(detrand.uniform("am", (n,), -0.1, 0.1)); v = torch.tensor(detrand.uniform("av", (n,), 0, 0.1))
+    t, lr = 3, 1e-3
+    e_th, e_m, e_v = R.adam_update(th.double(), g.double() * 0.5, m.double(), v.double(), t, lr)
+    lr_t = lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+    d = [a.clone().to(DEV) for a in (th, g, m, v)]
+    ops.adam(d[0], d[1], d[2], d[3], lr_t, grad_scale=0.5)
+    torch.cuda.synchronize()
+    close(d[0], e_th, 1e-6, "adam theta"); close(d[2], e_m, 1e-6, "adam m"); close(d[3], e_v, 1e-6, "adam v")
+
+    ws = ops.Workspace(DEV)
+    acc = torch.tensor([1.5], device=DEV)
+    ops.sumsq(d[1], 0.001, acc, True, ws)
+    x = torch.tensor(detrand.uniform("mx", (999,), -1, 1)); k = torch.tensor(detrand.uniform("mk", (999,), 0, 2))
+    y = torch.empty(999, device=DEV)
+    ops.mul(x.to(DEV), k.to(DEV), y)
+    nchw = torch.tensor(detrand.uniform("nx", (2, 2, 5, 7), 0, 1))
+    pa = ops.Act(torch.full((2, 5, 7, 4), 5.0, device=DEV))
+    ops.nchw_to_nhwc_pad(nchw.to(DEV), pa)
+    torch.cuda.synchronize()
+    assert abs(float(acc) - (1.5 + 0.001 * float((g.double() ** 2).sum()))) < 1e-5
+    assert torch.equal(y.cpu(), x * k)
+    assert torch.equal(pa.base[..., :2].cpu(), nchw.permute(0, 2, 3, 1)) and float(pa.base[..., 2:].abs().max()) == 0

@@ -1,0 +1,9 @@
+"""unet-rir_amd: MI355X (gfx950) implementation of the igmsalinas/unet-rir U-Net train-step hot path.
+
+Host side in Python over a C ABI (include/unetrir.h) of hand-written HIP kernels; PyTorch provides
+device memory, streams and torch.distributed only.
+"""
+from . import _lib, build, ops  # noqa: F401
+from ._lib import UnetrirError  # noqa: F401
+
+__all__ = ["ops", "build", "UnetrirError"]

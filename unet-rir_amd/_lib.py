@@ -1,0 +1,100 @@
+"""ctypes binding of libunetrir.so (the C ABI declared in include/unetrir.h).
+
+There is no CPU fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_stream = C.c_void_p
+
+
+class ConvGeom(C.Structure):
+    """unetrir_conv_geom"""
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("k", C.c_int), ("stride", C.c_int)]
+
+
+_SIGS = {
+    "unetrir_abi_version": (C.c_int, []),
+    "unetrir_conv2d_fwd_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int,
+                                         c_f32p, C.c_int, c_stream]),
+    "unetrir_conv2d_dgrad_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
+                                           C.c_int, c_stream]),
+    "unetrir_conv2d_wgrad_ws_bytes": (C.c_size_t, [C.POINTER(ConvGeom)]),
+    "unetrir_conv2d_wgrad_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_float,
+                                           c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_conv2d_transpose_fwd_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
+                                                   C.c_int, c_stream]),
+    "unetrir_conv2d_transpose_dgrad_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int,
+                                                     c_f32p, C.c_int, c_stream]),
+    "unetrir_conv2d_transpose_wgrad_ws_bytes": (C.c_size_t, [C.POINTER(ConvGeom)]),
+    "unetrir_conv2d_transpose_wgrad_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
+                                                     C.c_float, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_transpose_weight_f32": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "unetrir_bn_ws_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
+    "unetrir_bn_stats_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,
+                                       c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_bn_apply_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
+                                       c_stream]),
+    "unetrir_bn_bwd_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, c_f32p,
+                                     C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_colsum_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_void_p, C.c_size_t,
+                                     c_stream]),
+    "unetrir_relu_fwd_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int, c_stream]),
+    "unetrir_relu_bwd_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int,
+                                       c_stream]),
+    "unetrir_nchw_to_nhwc_pad_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
+                                               c_stream]),
+    "unetrir_loss_ws_bytes": (C.c_size_t, [C.c_longlong]),
+    "unetrir_sigmoid_loss_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                           c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_sigmoid_nchw_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "unetrir_sigmoid_bwd_f32": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "unetrir_embedding_fwd_f32": (C.c_int, [C.c_void_p, C.c_int, c_f32p, C.c_int, C.c_int, c_f32p, c_stream]),
+    "unetrir_embedding_bwd_f32": (C.c_int, [C.c_void_p, C.c_int, c_f32p, C.c_int, C.c_int, c_f32p, c_stream]),
+    "unetrir_mul_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_longlong, c_stream]),
+    "unetrir_sumsq_f32": (C.c_int, [c_f32p, C.c_longlong, C.c_float, c_f32p, C.c_int, C.c_void_p, C.c_size_t,
+                                    c_stream]),
+    "unetrir_adam_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_longlong, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, c_stream]),
+    "unetrir_prof_enable": (C.c_int, [C.c_int]),
+    "unetrir_prof_collect": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+EXPORTS = tuple(_SIGS)
+PROF_FAMILIES = 8
+
+
+class UnetrirError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (building first if the sources are newer) libunetrir.so.  Raises if it cannot."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if _build.needs_build():
+        path = _build.build()
+    if not os.path.exists(path):
+        raise UnetrirError(f"HIP extension missing: {path}")
+    L = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(L, name)      # AttributeError if the export is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if L.unetrir_abi_version() != 1:
+        raise UnetrirError("libunetrir.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def check(err, what):
+    if err != 0:
+        raise UnetrirError(f"{what} failed with code {err}")

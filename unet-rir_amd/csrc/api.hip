@@ -1,0 +1,252 @@
+// api.hip - the C ABI (include/unetrir.h): TF padding='same' geometry -> tap tables -> launches.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include "kernels.h"
+
+namespace {
+
+struct Same { int out, before; };
+// tf.nn.convolution padding='same': out = ceil(in/s), pad_total = max((out-1)*s + k - in, 0),
+// pad_before = pad_total / 2 (dl_models/u_net.py:269-276 relies on it for the strided convs).
+inline Same same_geom(int n_in, int k, int s) {
+    Same r;
+    r.out = (n_in + s - 1) / s;
+    int total = (r.out - 1) * s + k - n_in;
+    if (total < 0) total = 0;
+    r.before = total / 2;
+    return r;
+}
+
+inline uint32_t pack_tap(int dy, int dx, int widx) {
+    return (uint32_t)(uint8_t)(int8_t)dy | ((uint32_t)(uint8_t)(int8_t)dx << 8) | ((uint32_t)widx << 16);
+}
+
+inline bool geom_ok(const unetrir_conv_geom* g) {
+    return g && g->B > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0 && g->k >= 1 && g->k <= 6 &&
+           (g->stride == 1 || g->stride == 2);
+}
+
+// ---- profiling (the only process-global state in the library; off by default) ----
+struct ProfRec { int fam; hipEvent_t e0, e1; double flops; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    bool on; ProfRec r; hipStream_t s;
+    ProfScope(int fam, double flops, hipStream_t st) : on(g_prof_on), s(st) {
+        if (!on) return;
+        r.fam = fam; r.flops = flops;
+        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+        hipEventRecord(r.e0, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(r.e1, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(r);
+    }
+};
+
+inline double conv_flops(const unetrir_conv_geom* g) {
+    const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
+    return 2.0 * g->B * sy.out * sx.out * (double)g->Cout * g->Cin * g->k * g->k;
+}
+inline int conv_family(const unetrir_conv_geom* g, int fam) {
+    return (g->Cin < 8 || g->Cout < 8) ? 5 : fam;
+}
+
+// ---- Conv2D forward: iteration grid = output grid ----
+int conv_fwd_impl(const unetrir_conv_geom* g, const float* x, int ldx, const float* w, const float* bias,
+                  const float* addend, int ldadd, float* y, int ldy, hipStream_t s) {
+    const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
+    IgemmArgs a{};
+    a.g.B = g->B; a.g.PH = sy.out; a.g.PW = sx.out;
+    a.g.IH = g->H; a.g.IW = g->W; a.g.C = g->Cin; a.g.ldi = ldx;
+    a.g.OH = sy.out; a.g.OW = sx.out; a.g.N = g->Cout; a.g.ldo = ldy;
+    a.g.SI = g->stride; a.g.SO = 1; a.g.ooy = 0; a.g.oox = 0;
+    a.g.ntaps = g->k * g->k; a.g.wtaps = g->k * g->k;
+    for (int kh = 0; kh < g->k; ++kh)
+        for (int kw = 0; kw < g->k; ++kw)
+            a.g.tap[kh * g->k + kw] = pack_tap(kh - sy.before, kw - sx.before, kh * g->k + kw);
+    a.in = x; a.w = w; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = y;
+    return launch_igemm_fwd(a, s);
+}
+
+// ---- Conv2D data gradient (also Conv2DTranspose forward when `bias` is given) ----
+// dx[q][ci] = sum_t sum_co dy[p][co] * wt[ci][t][co]  with q = p*s + (k_t - pad_before)
+int conv_dgrad_impl(const unetrir_conv_geom* g, const float* dy, int lddy, const float* wt, const float* bias,
+                    const float* addend, int ldadd, float* dx, int lddx, hipStream_t s) {
+    const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
+    IgemmArgs a{};
+    a.g.B = g->B;
+    a.g.IH = sy.out; a.g.IW = sx.out; a.g.C = g->Cout; a.g.ldi = lddy;
+    a.g.OH = g->H; a.g.OW = g->W; a.g.N = g->Cin; a.g.ldo = lddx;
+    a.g.wtaps = g->k * g->k;
+    a.in = dy; a.w = wt; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = dx;
+    if (g->stride == 1) {
+        a.g.PH = g->H; a.g.PW = g->W; a.g.SI = 1; a.g.SO = 1; a.g.ooy = 0; a.g.oox = 0;
+        a.g.ntaps = g->k * g->k;
+        for (int kh = 0; kh < g->k; ++kh)
+            for (int kw = 0; kw < g->k; ++kw)
+                a.g.tap[kh * g->k + kw] = pack_tap(-(kh - sy.before), -(kw - sx.before), kh * g->k + kw);
+        return launch_igemm_fwd(a, s);
+    }
+    // stride 2: one launch per output parity class (ay, ax); q = 2p' + a, p = p' + (a - off)/2
+    a.g.PH = (g->H + 1) / 2; a.g.PW = (g->W + 1) / 2; a.g.SI = 1; a.g.SO = 2;
+    for (int ay = 0; ay < 2; ++ay)
+        for (int ax = 0; ax < 2; ++ax) {
+            int nt = 0;
+            for (int kh = 0; kh < g->k; ++kh) {
+                const int offy = kh - sy.before;
+                if (((offy - ay) & 1) != 0) continue;
+                for (int kw = 0; kw < g->k; ++kw) {
+                    const int offx = kw - sx.before;
+                    if (((offx - ax) & 1) != 0) continue;
+                    a.g.tap[nt++] = pack_tap((ay - offy) / 2, (ax - offx) / 2, kh * g->k + kw);
+                }
+            }
+            a.g.ntaps = nt; a.g.ooy = ay; a.g.oox = ax;
+            const int err = launch_igemm_fwd(a, s);
+            if (err) return err;
+        }
+    return 0;
+}
+
+void wgrad_args(const unetrir_conv_geom* g, int ldx, int lddy, WgradArgs* a) {
+    const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
+    a->g.B = g->B; a->g.PH = sy.out; a->g.PW = sx.out;
+    a->g.IH = g->H; a->g.IW = g->W; a->g.C = g->Cin; a->g.ldi = ldx;
+    a->g.N = g->Cout; a->g.SI = g->stride;
+    a->g.ntaps = g->k * g->k; a->g.wtaps = g->k * g->k;
+    for (int kh = 0; kh < g->k; ++kh)
+        for (int kw = 0; kw < g->k; ++kw)
+            a->g.tap[kh * g->k + kw] = pack_tap(kh - sy.before, kw - sx.before, kh * g->k + kw);
+    a->lddy = lddy;
+}
+
+size_t wgrad_ws_bytes(const unetrir_conv_geom* g) {
+    WgradArgs a{};
+    wgrad_args(g, g->Cin, g->Cout, &a);
+    int ns; long long per;
+    wgrad_plan(a.g, &ns, &per);
+    return (size_t)ns * g->Cout * g->k * g->k * g->Cin * sizeof(float);
+}
+
+int conv_wgrad_impl(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy, int lddy, float* dw,
+                    float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    WgradArgs a{};
+    wgrad_args(g, ldx, lddy, &a);
+    a.x = x; a.dy = dy;
+    return launch_igemm_wgrad(a, dw, reg, w, ws, ws_bytes, s);
+}
+
+// Conv2DTranspose(k, s=2, 'same') on an H x W input is the adjoint of Conv2D(k, s=2, 'same') that maps the
+// 2H x 2W grid back to H x W: swap the channel roles and double the spatial size.
+inline unetrir_conv_geom adjoint_geom(const unetrir_conv_geom* g) {
+    unetrir_conv_geom c = *g;
+    c.H = g->H * g->stride; c.W = g->W * g->stride;
+    c.Cin = g->Cout; c.Cout = g->Cin;
+    return c;
+}
+
+inline bool ld_ok(int ld, int c) { return ld >= c && (ld & 3) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int unetrir_abi_version(void) { return UNETRIR_ABI_VERSION; }
+
+int unetrir_conv2d_fwd_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* w, const float* bias,
+                           const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !w || !y || (g->Cin & 3) || !ld_ok(ldx, g->Cin) || ldy < g->Cout) return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
+    return conv_fwd_impl(g, x, ldx, w, bias, addend, ldadd, y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy, const float* wt,
+                             const float* addend, int ldadd, float* dx, int lddx, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !dy || !wt || !dx || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || lddx < g->Cin) return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
+    return conv_dgrad_impl(g, dy, lddy, wt, nullptr, addend, ldadd, dx, lddx, (hipStream_t)stream);
+}
+
+size_t unetrir_conv2d_wgrad_ws_bytes(const unetrir_conv_geom* g) { return geom_ok(g) ? wgrad_ws_bytes(g) : 0; }
+
+int unetrir_conv2d_wgrad_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy, int lddy, float* dw,
+                             float reg_coef, const float* w, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !dy || !dw || (g->Cin & 3) || !ld_ok(ldx, g->Cin) || (lddy & 3) || lddy < g->Cout ||
+        (reg_coef != 0.f && !w))
+        return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_WGRAD), conv_flops(g), (hipStream_t)stream);
+    return conv_wgrad_impl(g, x, ldx, dy, lddy, dw, reg_coef, w, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_transpose_fwd_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* wt,
+                                     const float* bias, float* y, int ldy, unetrir_stream_t stream) {
+    if (!geom_ok(g) || g->stride != 2 || !x || !wt || !y || (g->Cin & 3) || !ld_ok(ldx, g->Cin) || ldy < g->Cout)
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
+    return conv_dgrad_impl(&c, x, ldx, wt, bias, nullptr, 0, y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_transpose_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy, const float* w,
+                                       const float* addend, int ldadd, float* dx, int lddx, unetrir_stream_t stream) {
+    if (!geom_ok(g) || g->stride != 2 || !dy || !w || !dx || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || lddx < g->Cin)
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(&c), (hipStream_t)stream);
+    return conv_fwd_impl(&c, dy, lddy, w, nullptr, addend, ldadd, dx, lddx, (hipStream_t)stream);
+}
+
+size_t unetrir_conv2d_transpose_wgrad_ws_bytes(const unetrir_conv_geom* g) {
+    if (!geom_ok(g)) return 0;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    return wgrad_ws_bytes(&c);
+}
+
+int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy, int lddy,
+                                       float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
+                                       unetrir_stream_t stream) {
+    if (!geom_ok(g) || g->stride != 2 || !x || !dy || !dw || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || (ldx & 3) ||
+        ldx < g->Cin || (reg_coef != 0.f && !w))
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_WGRAD), conv_flops(&c), (hipStream_t)stream);
+    // adjoint conv: its "x" is our dy (2H x 2W, Cout channels), its "dy" is our x (H x W, Cin channels)
+    return conv_wgrad_impl(&c, dy, lddy, x, ldx, dw, reg_coef, w, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C, unetrir_stream_t stream) {
+    if (!w || !wt || N <= 0 || T <= 0 || C <= 0) return UNETRIR_EINVAL;
+    return launch_transpose_weight(w, wt, N, T, C, (hipStream_t)stream);
+}
+
+int unetrir_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    if (!g_prof_on) {
+        for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        g_prof.clear();
+    }
+    return 0;
+}
+
+int unetrir_prof_collect(int* counts, double* ms, double* flops) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < UNETRIR_PROF_FAMILIES; ++i) { counts[i] = 0; ms[i] = 0.0; flops[i] = 0.0; }
+    for (auto& r : g_prof) {
+        hipEventSynchronize(r.e1);
+        float t = 0.f;
+        hipEventElapsedTime(&t, r.e0, r.e1);
+        if (r.fam >= 0 && r.fam < UNETRIR_PROF_FAMILIES) { counts[r.fam]++; ms[r.fam] += t; flops[r.fam] += r.flops; }
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,552 @@
+// elementwise.hip - the HBM-bound kernels of the train step (gfx950): BatchNorm statistics /
+// apply / backward, bias gradients, sigmoid + amp/phase loss, embedding, Adam, layout helpers.
+// Every reduction is two-stage with a fixed summation order (no float atomics): results are
+// bit-reproducible run to run.  Per-channel sums accumulate in fp64 (the VALU has the headroom:
+// these kernels are bound by HBM bytes, not by flops).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "kernels.h"
+
+namespace {
+
+struct ChanPlan { int QB, RB, ngroups, nslab; long long rows_per_slab; };
+
+// Thread layout for [P][C] per-channel reductions: QB channel-quads x RB pixel rows per block.
+inline ChanPlan chan_plan(long long P, int C) {
+    ChanPlan p;
+    const int CQ = C / 4;
+    int qb = 1;
+    while (qb * 2 <= CQ && qb * 2 <= 256) qb *= 2;
+    p.QB = qb; p.RB = 256 / qb;
+    p.ngroups = (CQ + qb - 1) / qb;
+    long long want = 2048 / p.ngroups;                    // ~2048 blocks in flight
+    if (want < 1) want = 1;
+    long long min_rows = (long long)p.RB * 8;             // at least 8 rows per thread
+    long long maxslab = (P + min_rows - 1) / min_rows;
+    if (maxslab < 1) maxslab = 1;
+    if (want > maxslab) want = maxslab;
+    p.rows_per_slab = (P + want - 1) / want;
+    p.nslab = (int)((P + p.rows_per_slab - 1) / p.rows_per_slab);
+    return p;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------
+// stage 1: per-slab per-channel partial sums.  MODE 0: (sum x, sum x^2)   [BN statistics]
+//                                               MODE 1: (sum x, -)         [bias gradient]
+//                                               MODE 2: (sum g, sum g*xhat) with g = da*[relu mask]
+// partial layout: double part[nslab][C][2]
+// -------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ da, int ldda,
+                                                           const float* __restrict__ affine,
+                                                           const float* __restrict__ saved, int relu,
+                                                           long long P, int C, int QB, long long rows_per_slab,
+                                                           double* __restrict__ part) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int RB = 256 / QB;
+    const int ql = tid % QB, rl = tid / QB;
+    const int q = blockIdx.y * QB + ql;
+    const int c0 = q * 4;
+    const bool cok = c0 < C;
+    const long long p0 = (long long)blockIdx.x * rows_per_slab;
+    long long p1 = p0 + rows_per_slab;
+    if (p1 > P) p1 = P;
+
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    float sc[4] = {1, 1, 1, 1}, sh[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
+    if (MODE == 2 && cok) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sc[k] = affine[c0 + k]; sh[k] = affine[C + c0 + k];
+            mu[k] = saved[c0 + k]; rs[k] = saved[C + c0 + k];
+        }
+    }
+    if (cok) {
+        for (long long p = p0 + rl; p < p1; p += RB) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ldx + c0);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            if (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const double d = xv[k]; s0[k] += d; s1[k] += d * d; }
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s0[k] += (double)xv[k];
+            } else {
+                const float4 gq = *reinterpret_cast<const float4*>(da + (size_t)p * ldda + c0);
+                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = xv[k] * sc[k] + sh[k];
+                    const float g = (relu && !(a > 0.f)) ? 0.f : gv[k];
+                    const float xh = (xv[k] - mu[k]) * rs[k];
+                    s0[k] += (double)g; s1[k] += (double)g * (double)xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s0[k]; red[tid * 8 + 4 + k] = s1[k]; }
+    __syncthreads();
+    if (rl == 0 && cok) {
+        for (int r = 1; r < RB; ++r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s0[k] += red[(r * QB + ql) * 8 + k];
+                s1[k] += red[(r * QB + ql) * 8 + 4 + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            part[((size_t)blockIdx.x * C + c0 + k) * 2 + 0] = s0[k];
+            part[((size_t)blockIdx.x * C + c0 + k) * 2 + 1] = s1[k];
+        }
+    }
+}
+
+// stage 2 (BN statistics): mean / biased variance -> affine, saved, moving statistics
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                   float* __restrict__ affine, float* __restrict__ saved) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int k = 0; k < nslab; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+    const double mean = s / (double)P;
+    double var = ss / (double)P - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float scale = g * rstd;
+    affine[c] = scale;
+    affine[C + c] = b - (float)mean * scale;
+    saved[c] = (float)mean;
+    saved[C + c] = rstd;
+    if (moving_mean) moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
+    if (moving_var) {
+        const double unb = P > 1 ? var * (double)P / (double)(P - 1) : var;
+        moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unb;
+    }
+}
+
+// stage 2 (column sum): out[c] = sum_slabs
+__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nslab, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int k = 0; k < nslab; ++k) s += part[((size_t)k * C + c) * 2];
+    out[c] = (float)s;
+}
+
+// stage 2 (BN backward): dgamma, dbeta and the two means the dx pass needs -> coef[2*C]
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int k = 0; k < nslab; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)ss;
+    coef[c] = (float)(s / (double)P);
+    coef[C + c] = (float)(ss / (double)P);
+}
+
+// y = x*scale + shift (ReLU optional), float4 over [P][C]
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, long long P, int C,
+                                                       const float* __restrict__ affine, int relu,
+                                                       float* __restrict__ y, int ldy) {
+    const int CQ = C / 4;
+    const long long total = P * CQ;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / CQ;
+        const int c0 = (int)(i - p * CQ) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ldx + c0);
+        float4 r;
+        if (affine) {
+            const float4 sc = *reinterpret_cast<const float4*>(affine + c0);
+            const float4 sh = *reinterpret_cast<const float4*>(affine + C + c0);
+            r.x = v.x * sc.x + sh.x; r.y = v.y * sc.y + sh.y; r.z = v.z * sc.z + sh.z; r.w = v.w * sc.w + sh.w;
+        } else {
+            r = v;
+        }
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        *reinterpret_cast<float4*>(y + (size_t)p * ldy + c0) = r;
+    }
+}
+
+// dx = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = da * relu-mask;  without BN (affine == NULL): dx = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda,
+                                                           const float* __restrict__ x, int ldx, long long P, int C,
+                                                           const float* __restrict__ affine,
+                                                           const float* __restrict__ saved,
+                                                           const float* __restrict__ coef, int relu,
+                                                           float* __restrict__ dx, int lddx) {
+    const int CQ = C / 4;
+    const long long total = P * CQ;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / CQ;
+        const int c0 = (int)(i - p * CQ) * 4;
+        const float4 xv4 = *reinterpret_cast<const float4*>(x + (size_t)p * ldx + c0);
+        const float4 gv4 = *reinterpret_cast<const float4*>(da + (size_t)p * ldda + c0);
+        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
+        float out[4];
+        if (affine) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sc = affine[c0 + k], sh = affine[C + c0 + k];
+                const float a = xv[k] * sc + sh;
+                const float g = (relu && !(a > 0.f)) ? 0.f : gv[k];
+                const float xh = (xv[k] - saved[c0 + k]) * saved[C + c0 + k];
+                out[k] = sc * (g - coef[c0 + k] - xh * coef[C + c0 + k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = (relu && !(xv[k] > 0.f)) ? 0.f : gv[k];
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)p * lddx + c0) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// boundary: NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] (zero fill), one thread per pixel
+// -------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int C, int H, int W,
+                                        float* __restrict__ y, int Cpad) {
+    const long long hw = (long long)H * W, total = (long long)B * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, r = i - b * hw;
+        for (int c = 0; c < Cpad; ++c) y[i * Cpad + c] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// sigmoid + amplitude/phase loss (main_training.py:184-235) + dL/dlogits, one thread per pixel
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ __launch_bounds__(256) void sigmoid_loss_kernel(const float* __restrict__ logits, int ldl,
+                                                           const float* __restrict__ target, int B, int H, int W,
+                                                           float alpha, float inv_norm, float* __restrict__ pred,
+                                                           float* __restrict__ dlogits, double* __restrict__ part) {
+    __shared__ double red[256 * 2];
+    const long long hw = (long long)H * W, total = (long long)B * hw;
+    const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
+    double sa = 0, sp = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, r = i - b * hw;
+        const float p0 = sigmoidf_(logits[i * ldl + 0]), p1 = sigmoidf_(logits[i * ldl + 1]);
+        pred[(b * 2 + 0) * hw + r] = p0;
+        pred[(b * 2 + 1) * hw + r] = p1;
+        if (target) {
+            const float t0 = target[(b * 2 + 0) * hw + r], t1 = target[(b * 2 + 1) * hw + r];
+            const float da = t0 - p0;
+            const float yt = t1 * TWO_PI - PI, yp = p1 * TWO_PI - PI;
+            const float d = (yt - yp) + PI;
+            const float ph = (d - floorf(d / TWO_PI) * TWO_PI) - PI;     // python-style modulo
+            sa += (double)(da * da);
+            sp += (double)(1.f - cosf(ph));
+            const float g0 = -2.f * da * alpha * inv_norm;
+            const float g1 = -(1.f - alpha) * inv_norm * TWO_PI * sinf(ph);
+            *reinterpret_cast<float4*>(dlogits + i * 4) =
+                make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f);
+        }
+    }
+    red[threadIdx.x * 2] = sa; red[threadIdx.x * 2 + 1] = sp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 256; ++k) { sa += red[k * 2]; sp += red[k * 2 + 1]; }
+        part[blockIdx.x * 2] = sa; part[blockIdx.x * 2 + 1] = sp;
+    }
+}
+
+__global__ void loss_finalize_kernel(const double* __restrict__ part, int nblk, float alpha, float inv_norm,
+                                     float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sa = 0, sp = 0;
+    for (int k = 0; k < nblk; ++k) { sa += part[k * 2]; sp += part[k * 2 + 1]; }
+    out[0] = (float)(((double)alpha * sa + (1.0 - (double)alpha) * sp) * (double)inv_norm);
+    out[1] = (float)sa;
+    out[2] = (float)sp;
+}
+
+__global__ void sigmoid_only_kernel(const float* __restrict__ logits, int ldl, int B, int H, int W,
+                                    float* __restrict__ pred) {
+    const long long hw = (long long)H * W, total = (long long)B * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, r = i - b * hw;
+        pred[(b * 2 + 0) * hw + r] = sigmoidf_(logits[i * ldl + 0]);
+        pred[(b * 2 + 1) * hw + r] = sigmoidf_(logits[i * ldl + 1]);
+    }
+}
+
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ dpred, int B, int H,
+                                   int W, float* __restrict__ dlogits) {
+    const long long hw = (long long)H * W, total = (long long)B * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, r = i - b * hw;
+        const float p0 = pred[(b * 2 + 0) * hw + r], p1 = pred[(b * 2 + 1) * hw + r];
+        const float g0 = dpred[(b * 2 + 0) * hw + r], g1 = dpred[(b * 2 + 1) * hw + r];
+        *reinterpret_cast<float4*>(dlogits + i * 4) = make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Embedding gather and its deterministic gradient
+// -------------------------------------------------------------------------------------------
+__global__ void embedding_fwd_kernel(const int* __restrict__ idx, int n_idx, const float* __restrict__ table,
+                                     int vocab, int dim, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    int v = idx[i];
+    v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+    for (int d = threadIdx.x; d < dim; d += blockDim.x) out[(size_t)i * dim + d] = table[(size_t)v * dim + d];
+}
+
+__global__ void embedding_bwd_kernel(const int* __restrict__ idx, int n_idx, const float* __restrict__ dout,
+                                     int vocab, int dim, float* __restrict__ dtable) {
+    const int v = blockIdx.x;
+    for (int d = threadIdx.x; d < dim; d += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < n_idx; ++i) {
+            int u = idx[i];
+            u = u < 0 ? 0 : (u >= vocab ? vocab - 1 : u);
+            if (u == v) s += dout[(size_t)i * dim + d];
+        }
+        dtable[(size_t)v * dim + d] = s;
+    }
+}
+
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = x[i] * m[i];
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, long long n, double* __restrict__ part) {
+    __shared__ double red[256];
+    double s = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 256; ++k) s += red[k];
+        part[blockIdx.x] = s;
+    }
+}
+
+__global__ void sumsq_finalize_kernel(const double* __restrict__ part, int nblk, float coef, float* __restrict__ out, int accumulate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0;
+    for (int k = 0; k < nblk; ++k) s += part[k];
+    const float r = (float)((double)coef * s);
+    out[0] = accumulate ? out[0] + r : r;
+}
+
+// Keras Adam: m,v update; theta -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float lr_t, float b1, float b2, float eps, float gs) {
+    const long long n4 = n / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 t = reinterpret_cast<float4*>(theta)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* tp = &t.x; const float* gp = &gg.x; float* mp = &mm.x; float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gp[k] * gs;
+            mp[k] = b1 * mp[k] + (1.f - b1) * gk;
+            vp[k] = b2 * vp[k] + (1.f - b2) * gk * gk;
+            tp[k] -= lr_t * mp[k] / (sqrtf(vp[k]) + eps);
+        }
+        reinterpret_cast<float4*>(theta)[i] = t;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (long long i = n4 * 4; i < n; ++i) {
+            const float gk = g[i] * gs;
+            m[i] = b1 * m[i] + (1.f - b1) * gk;
+            v[i] = b2 * v[i] + (1.f - b2) * gk * gk;
+            theta[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------
+static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096) {
+    long long b = (n + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+static inline bool chan_ok(const void* x, int ld, long long P, int C) { return x && P > 0 && C > 0 && (C & 3) == 0 && ld >= C && (ld & 3) == 0; }
+
+extern "C" {
+
+size_t unetrir_bn_ws_bytes(long long P, int C) {
+    if (P <= 0 || C <= 0) return 0;
+    const ChanPlan pl = chan_plan(P, C);
+    return ((size_t)pl.nslab * C * 2) * sizeof(double) + (size_t)2 * C * sizeof(float);
+}
+
+int unetrir_bn_stats_f32(const float* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps,
+                         float momentum, float* moving_mean, float* moving_var, float* affine, float* saved, void* ws,
+                         size_t ws_bytes, unetrir_stream_t stream) {
+    if (!chan_ok(x, ldx, P, C) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const float*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
+                       beta, eps, momentum, moving_mean, moving_var, affine, saved);
+    return (int)hipGetLastError();
+}
+
+int unetrir_bn_apply_f32(const float* x, int ldx, long long P, int C, const float* affine, int relu, float* y, int ldy,
+                         unetrir_stream_t stream) {
+    if (!chan_ok(x, ldx, P, C) || !y || ldy < C || (ldy & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, P, C, affine,
+                       relu, y, ldy);
+    return (int)hipGetLastError();
+}
+
+int unetrir_bn_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C, const float* gamma,
+                       const float* affine, const float* saved, int relu, float* dx, int lddx, float* dgamma,
+                       float* dbeta, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    (void)gamma;
+    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3) || !affine || !saved || !ws ||
+        ws_bytes < unetrir_bn_ws_bytes(P, C))
+        return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C);
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)ws;
+    float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
+    hipLaunchKernelGGL(chan_partial_kernel<2>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
+                       relu, P, C, pl.QB, pl.rows_per_slab, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)part, pl.nslab, P, C,
+                       dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
+                       (const float*)coef, relu, dx, lddx);
+    return (int)hipGetLastError();
+}
+
+int unetrir_colsum_f32(const float* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes,
+                       unetrir_stream_t stream) {
+    if (!chan_ok(x, ldx, P, C) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const float*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out);
+    return (int)hipGetLastError();
+}
+
+int unetrir_relu_fwd_f32(const float* x, int ldx, long long P, int C, float* y, int ldy, unetrir_stream_t stream) {
+    return unetrir_bn_apply_f32(x, ldx, P, C, nullptr, 1, y, ldy, stream);
+}
+
+int unetrir_relu_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C, float* dx, int lddx,
+                         unetrir_stream_t stream) {
+    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda, x, ldx,
+                       P, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1, dx, lddx);
+    return (int)hipGetLastError();
+}
+
+int unetrir_nchw_to_nhwc_pad_f32(const float* x, int B, int C, int H, int W, float* y, int Cpad, unetrir_stream_t stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B,
+                       C, H, W, y, Cpad);
+    return (int)hipGetLastError();
+}
+
+#define LOSS_BLOCKS 1024
+size_t unetrir_loss_ws_bytes(long long npix) { (void)npix; return (size_t)LOSS_BLOCKS * 2 * sizeof(double); }
+
+int unetrir_sigmoid_loss_f32(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha,
+                             float inv_norm, float* pred, float* dlogits, float* loss_out, void* ws, size_t ws_bytes,
+                             unetrir_stream_t stream) {
+    if (!logits || ldl < 2 || !target || !pred || !dlogits || !loss_out || !ws || ws_bytes < unetrir_loss_ws_bytes(0) ||
+        B <= 0 || H <= 0 || W <= 0)
+        return UNETRIR_EINVAL;
+    const unsigned nb = grid_for((long long)B * H * W, 256, LOSS_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sigmoid_loss_kernel, dim3(nb), dim3(256), 0, s, logits, ldl, target, B, H, W, alpha, inv_norm, pred,
+                       dlogits, (double*)ws);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, alpha, inv_norm, loss_out);
+    return (int)hipGetLastError();
+}
+
+int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, float* pred, unetrir_stream_t stream) {
+    if (!logits || ldl < 2 || !pred || B <= 0 || H <= 0 || W <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_only_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, logits,
+                       ldl, B, H, W, pred);
+    return (int)hipGetLastError();
+}
+
+int unetrir_sigmoid_bwd_f32(const float* pred, const float* dpred, int B, int H, int W, float* dlogits,
+                            unetrir_stream_t stream) {
+    if (!pred || !dpred || !dlogits || B <= 0 || H <= 0 || W <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, pred, dpred,
+                       B, H, W, dlogits);
+    return (int)hipGetLastError();
+}
+
+int unetrir_embedding_fwd_f32(const int* idx, int n_idx, const float* table, int vocab, int dim, float* out,
+                              unetrir_stream_t stream) {
+    if (!idx || !table || !out || n_idx <= 0 || vocab <= 0 || dim <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(n_idx), dim3(256), 0, (hipStream_t)stream, idx, n_idx, table, vocab, dim, out);
+    return (int)hipGetLastError();
+}
+
+int unetrir_embedding_bwd_f32(const int* idx, int n_idx, const float* dout, int vocab, int dim, float* dtable,
+                              unetrir_stream_t stream) {
+    if (!idx || !dout || !dtable || n_idx <= 0 || vocab <= 0 || dim <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)stream, idx, n_idx, dout, vocab, dim,
+                       dtable);
+    return (int)hipGetLastError();
+}
+
+int unetrir_mul_f32(const float* x, const float* m, float* y, long long n, unetrir_stream_t stream) {
+    if (!x || !m || !y || n <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, m, y, n);
+    return (int)hipGetLastError();
+}
+
+#define SUMSQ_BLOCKS 512
+int unetrir_sumsq_f32(const float* x, long long n, float coef, float* out, int accumulate, void* ws, size_t ws_bytes,
+                      unetrir_stream_t stream) {
+    if (!x || !out || n <= 0 || !ws || ws_bytes < SUMSQ_BLOCKS * sizeof(double)) return UNETRIR_EINVAL;
+    const unsigned nb = grid_for(n, 256, SUMSQ_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, x, n, (double*)ws);
+    hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, coef, out, accumulate);
+    return (int)hipGetLastError();
+}
+
+int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long n, float lr_t, float beta1, float beta2,
+                     float eps, float grad_scale, unetrir_stream_t stream) {
+    if (!theta || !g || !m || !v || n <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n,
+                       lr_t, beta1, beta2, eps, grad_scale);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

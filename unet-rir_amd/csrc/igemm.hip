@@ -1,0 +1,418 @@
+// igemm.hip - implicit-GEMM convolution kernels for gfx950 (MI355X), fp32 MFMA.
+//
+// One forward-type kernel covers Conv2D (stride 1|2), Conv2DTranspose (as 4 output-parity
+// sub-convolutions) and every data gradient; one weight-gradient kernel covers every dW.
+// Both are driven by a small tap table (TF padding='same' geometry is resolved on the host
+// in api.hip), replace what TensorFlow dispatches to cuDNN for dl_models/u_net.py:269-276,
+// :297-304, :366, :248, :262 and their tape.gradient counterparts (main_training.py:267).
+//
+// Math: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD).  A = activations
+// (rows = pixels), B = weights (cols = output channels), so the accumulator has the output
+// channel on the lane and the NHWC store is 128 contiguous bytes per (row, half-wave).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128          // pixels per tile
+#define BK 32           // k (tap, channel) values per LDS stage
+#define LDS_LD 36       // padded row length (floats): 9 x 16 B, odd -> conflict-free ds_read_b128
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // Blocks are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles so
+    // neighbouring pixel tiles (shared halo rows, shared weight panel) meet in one L2.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward-type kernel:  out[opix(p)][n] = bias[n] + addend + sum_t sum_c in[ipix(p,t)][c] * w[n][widx_t][c]
+// ------------------------------------------------------------------------------------------------
+template <int BN_>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
+    constexpr int NSUB = BN_ / 64;        // 32-wide N sub-tiles per wave (waves are 2 x 2)
+    constexpr int NB = BN_ / 32;          // B-tile rows loaded per thread
+    __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN_ * LDS_LD];
+    __shared__ uint32_t s_tap[UNETRIR_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    if (tid < UNETRIR_MAX_TAPS) s_tap[tid] = a.g.tap[tid];
+
+    const int ntN = (a.g.N + BN_ - 1) / BN_;
+    const int nwg = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int mt = id / ntN, nt = id - mt * ntN;
+    const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN_;
+
+    const int C = a.g.C, ntaps = a.g.ntaps;
+    const int IH = a.g.IH, IW = a.g.IW, ldi = a.g.ldi;
+    const int ldw = a.g.wtaps * C;
+    const int Ktot = ntaps * C;
+    const int nch = (Ktot + BK - 1) / BK;
+
+    // loader mapping: 8 threads cover the 32 k-values of one row; 32 rows per pass
+    const int quad = tid & 7, lrow = tid >> 3;
+    int kt = (quad * 4) / C, kc = (quad * 4) % C;          // (tap, channel) of this thread's k-quad
+
+    int a_by[4], a_bx[4], a_img[4];
+    const int plane = a.g.PH * a.g.PW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = m0 + lrow + 32 * j;
+        if (p < M) {
+            const int n = (int)(p / plane);
+            const int rem = (int)(p - (long long)n * plane);
+            const int py = rem / a.g.PW, px = rem - py * a.g.PW;
+            a_by[j] = py * a.g.SI; a_bx[j] = px * a.g.SI; a_img[j] = n * IH;
+        } else {
+            a_by[j] = -(1 << 28); a_bx[j] = 0; a_img[j] = 0;   // always out of range -> zero fill
+        }
+    }
+
+    float4 ra[4], rb[NB];
+    __syncthreads();   // s_tap visible
+
+    auto load_stage = [&]() {
+        const bool kok = kt < ntaps;
+        const uint32_t e = kok ? s_tap[kt] : 0u;
+        const int dy = (int)(int8_t)(e & 0xff), dx = (int)(int8_t)((e >> 8) & 0xff);
+        const int wi = (int)((e >> 16) & 0xff);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_by[j] + dy, ix = a_bx[j] + dx;
+            const bool ok = kok && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4*>(a.in + ((size_t)(a_img[j] + iy) * IW + ix) * ldi + kc);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + lrow + 32 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kok && n < a.g.N) v = *reinterpret_cast<const float4*>(a.w + (size_t)n * ldw + wi * C + kc);
+            rb[j] = v;
+        }
+    };
+
+    f32x16 acc[2][NSUB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_stage();
+    const int arow = wm * 64 + (lane & 31), brow = wn * (BN_ / 2) + (lane & 31);
+    const int koff = (lane >> 5) * 4;
+
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[(lrow + 32 * j) * LDS_LD + quad * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<float4*>(&Bs[(lrow + 32 * j) * LDS_LD + quad * 4]) = rb[j];
+        __syncthreads();
+        if (ch + 1 < nch) {
+            kc += BK;
+            while (kc >= C) { kc -= C; ++kt; }
+            load_stage();
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float4 fa[2], fb[NSUB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4*>(&As[(arow + 32 * i) * LDS_LD + kk * 8 + koff]);
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) fb[j] = *reinterpret_cast<const float4*>(&Bs[(brow + 32 * j) * LDS_LD + kk * 8 + koff]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: accumulator (col = lane&31 -> n, row = (r&3)+8*(r>>2)+4*(lane>>5) -> pixel)
+    const bool simple = (a.g.SO == 1 && a.g.ooy == 0 && a.g.oox == 0 && a.g.OH == a.g.PH && a.g.OW == a.g.PW);
+    float bias[NSUB];
+    int ncol[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        ncol[j] = n0 + wn * (BN_ / 2) + 32 * j + (lane & 31);
+        bias[j] = (a.bias != nullptr && ncol[j] < a.g.N) ? a.bias[ncol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const long long p = m0 + row;
+            if (p >= M) continue;
+            long long opix;
+            if (simple) {
+                opix = p;
+            } else {
+                const int n = (int)(p / plane);
+                const int rem = (int)(p - (long long)n * plane);
+                const int py = rem / a.g.PW, px = rem - py * a.g.PW;
+                const int oy = py * a.g.SO + a.g.ooy, ox = px * a.g.SO + a.g.oox;
+                if (oy >= a.g.OH || ox >= a.g.OW) continue;
+                opix = ((long long)n * a.g.OH + oy) * a.g.OW + ox;
+            }
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                if (ncol[j] < a.g.N) {
+                    float v = acc[i][j][r] + bias[j];
+                    if (a.addend != nullptr) v += a.addend[opix * a.ldadd + ncol[j]];
+                    a.out[opix * a.g.ldo + ncol[j]] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel: part[s][n][widx_t*C + c] = sum_{p in slice s} dy[p][n] * x[ipix(p,t)][c]
+// GEMM rows = output channels n, cols = flattened (tap, channel), K = pixels (split over blockIdx.y)
+// ------------------------------------------------------------------------------------------------
+#define WG_COLS 128
+#define WG_PIX 32
+#define WG_LDX (WG_COLS + 4)
+
+template <int BR_>   // rows (output channels) per tile: 64 or 128
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
+    constexpr int MSUB = BR_ / 64;        // BR_=128: waves 2x2 of 64x64; BR_=64: waves 2x2 of 32x64
+    constexpr int LDD = BR_ + 4;
+    constexpr int DQ = BR_ / 4;           // dy quads per pixel row
+    constexpr int DPASS = (WG_PIX * DQ) / 256;
+    constexpr int DROWS = 256 / DQ;
+    __shared__ __attribute__((aligned(16))) float Ds[WG_PIX * LDD];
+    __shared__ __attribute__((aligned(16))) float Xs[WG_PIX * WG_LDX];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int C = a.g.C;
+    const int Kc = a.g.ntaps * C;                 // valid columns
+    const int ntC = (Kc + WG_COLS - 1) / WG_COLS;
+    const int id = blockIdx.x;
+    const int rt = id / ntC, ct = id - rt * ntC;  // column tile fastest: shares the dy panel in L2
+    const int n0 = rt * BR_, j0 = ct * WG_COLS;
+    const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
+    const long long chunk_per = a.chunks_per_split;
+    const long long pk0 = (long long)blockIdx.y * chunk_per * WG_PIX;
+    long long pk1 = pk0 + chunk_per * WG_PIX;
+    if (pk1 > M) pk1 = M;
+
+    // X loader: this thread always loads the same 4 columns -> fixed (tap, channel)
+    const int xq = tid & 31, xr = tid >> 5;      // 32 quads per row, 8 rows per pass
+    const int col = j0 + xq * 4;
+    const bool colok = col < Kc;
+    const int t = colok ? col / C : 0, c = colok ? col - (col / C) * C : 0;
+    const uint32_t e = a.g.tap[t];
+    const int dy = (int)(int8_t)(e & 0xff), dx = (int)(int8_t)((e >> 8) & 0xff);
+    const int plane = a.g.PH * a.g.PW;
+    const int IH = a.g.IH, IW = a.g.IW, SI = a.g.SI;
+
+    const int dq = tid % DQ, dr = tid / DQ;
+    const bool nok = (n0 + dq * 4) < a.g.N;
+
+    float4 rx[4], rd[DPASS];
+    auto load_stage = [&](long long pk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long p = pk + xr + 8 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (colok && p < pk1) {
+                const int n = (int)(p / plane);
+                const int rem = (int)(p - (long long)n * plane);
+                const int py = rem / a.g.PW, px = rem - py * a.g.PW;
+                const int iy = py * SI + dy, ix = px * SI + dx;
+                if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
+                    v = *reinterpret_cast<const float4*>(a.x + ((size_t)((long long)n * IH + iy) * IW + ix) * a.g.ldi + c);
+            }
+            rx[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < DPASS; ++j) {
+            const long long p = pk + dr + DROWS * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nok && p < pk1) v = *reinterpret_cast<const float4*>(a.dy + (size_t)p * a.lddy + n0 + dq * 4);
+            rd[j] = v;
+        }
+    };
+
+    f32x16 acc[MSUB][2];
+#pragma unroll
+    for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = wm * (BR_ / 2) + (lane & 31);   // output-channel row inside the tile
+    const int bcol = wn * 64 + (lane & 31);
+    const int kh = lane >> 5;
+
+    if (pk0 < pk1) load_stage(pk0);
+    for (long long pk = pk0; pk < pk1; pk += WG_PIX) {
+        if (pk != pk0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&Xs[(xr + 8 * j) * WG_LDX + xq * 4]) = rx[j];
+#pragma unroll
+        for (int j = 0; j < DPASS; ++j) *reinterpret_cast<float4*>(&Ds[(dr + DROWS * j) * LDD + dq * 4]) = rd[j];
+        __syncthreads();
+        if (pk + WG_PIX < pk1) load_stage(pk + WG_PIX);
+#pragma unroll
+        for (int s = 0; s < WG_PIX / 2; ++s) {
+            float fa[MSUB], fb[2];
+#pragma unroll
+            for (int i = 0; i < MSUB; ++i) fa[i] = Ds[(2 * s + kh) * LDD + arow + 32 * i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Xs[(2 * s + kh) * WG_LDX + bcol + 32 * j];
+#pragma unroll
+            for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: rows (registers) = output channel, cols (lanes) = flattened (tap, channel)
+    float* part = a.part + (size_t)blockIdx.y * a.g.N * ((size_t)a.g.wtaps * C);
+    const size_t ldp = (size_t)a.g.wtaps * C;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cc = j0 + wn * 64 + 32 * j + (lane & 31);
+        if (cc >= Kc) continue;
+        const int tt = cc / C, c2 = cc - tt * C;
+        const size_t ocol = (size_t)((a.g.tap[tt] >> 16) & 0xff) * C + c2;
+#pragma unroll
+        for (int i = 0; i < MSUB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wm * (BR_ / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < a.g.N) part[(size_t)n * ldp + ocol] = acc[i][j][r];
+            }
+    }
+}
+
+// out[i] = sum_s part[s][i] + reg * w[i]
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
+                                     float* __restrict__ out, float reg, const float* __restrict__ w) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (reg != 0.f) {
+            const float4 v = *reinterpret_cast<const float4*>(w + i4);
+            s.x += reg * v.x; s.y += reg * v.y; s.z += reg * v.z; s.w += reg * v.w;
+        }
+        *reinterpret_cast<float4*>(out + i4) = s;
+    } else {
+        for (size_t i = i4; i < n; ++i) {
+            float s = 0.f;
+            for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
+            if (reg != 0.f) s += reg * w[i];
+            out[i] = s;
+        }
+    }
+}
+
+// [N][T][C] -> [C][T][N] through a 32x33 LDS tile per tap
+__global__ void transpose_weight_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int T, int C) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, c = c0 + tx;
+        tile[r][tx] = (n < N && c < C) ? w[((size_t)n * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, n = n0 + tx;
+        if (n < N && c < C) wt[((size_t)c * T + t) * N + n] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+int launch_igemm_fwd(const IgemmArgs& a, hipStream_t s) {
+    const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
+    if (M <= 0 || a.g.N <= 0) return 0;
+    const long long mt = (M + BM - 1) / BM;
+    if (a.g.N > 64) {
+        const long long nwg = mt * ((a.g.N + 127) / 128);
+        hipLaunchKernelGGL(igemm_fwd_kernel<128>, dim3((unsigned)nwg), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(igemm_fwd_kernel<64>, dim3((unsigned)mt), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int wgrad_plan(const IgemmGeom& g, int* nsplit, long long* chunks_per_split) {
+    const long long M = (long long)g.B * g.PH * g.PW;
+    const long long nchunks = (M + WG_PIX - 1) / WG_PIX;
+    const int br = g.N > 64 ? 128 : 64;
+    const long long tiles = (long long)((g.N + br - 1) / br) * ((g.ntaps * g.C + WG_COLS - 1) / WG_COLS);
+    long long want = (1024 + tiles - 1) / tiles;          // aim at >= 1024 workgroups
+    long long maxs = (nchunks + 7) / 8;                   // at least 8 chunks (256 pixels) per slice
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    long long per = (nchunks + want - 1) / want;
+    long long ns = (nchunks + per - 1) / per;
+    *nsplit = (int)ns;
+    *chunks_per_split = per;
+    return 0;
+}
+
+int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    int nsplit; long long per;
+    wgrad_plan(a.g, &nsplit, &per);
+    const size_t nout = (size_t)a.g.N * a.g.wtaps * a.g.C;
+    const bool direct = (nsplit == 1 && reg == 0.f);
+    if (!direct && ws_bytes < (size_t)nsplit * nout * sizeof(float)) return UNETRIR_EINVAL;
+    a.part = direct ? dw : (float*)ws;
+    a.chunks_per_split = per;
+    const int br = a.g.N > 64 ? 128 : 64;
+    const unsigned tiles = (unsigned)(((a.g.N + br - 1) / br) * ((a.g.ntaps * a.g.C + WG_COLS - 1) / WG_COLS));
+    if (br == 128) hipLaunchKernelGGL(igemm_wgrad_kernel<128>, dim3(tiles, nsplit), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(igemm_wgrad_kernel<64>, dim3(tiles, nsplit), dim3(256), 0, s, a);
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    if (!direct) {
+        const size_t nthreads = (nout + 3) / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
+                           (const float*)ws, nsplit, nout, dw, reg, w);
+        err = (int)hipGetLastError();
+    }
+    return err;
+}
+
+int launch_transpose_weight(const float* w, float* wt, int N, int T, int C, hipStream_t s) {
+    dim3 grid((C + 31) / 32, (N + 31) / 32, T);
+    hipLaunchKernelGGL(transpose_weight_kernel, grid, dim3(256), 0, s, w, wt, N, T, C);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,243 @@
+"""Host-side operator wrappers: torch tensors (device memory, streams) -> the C ABI.
+
+Each function mirrors one Keras call site of the reference graph and forwards to the HIP
+library.  PyTorch is used for device memory and streams only; no arithmetic happens here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, check
+
+
+class Act:
+    """An NHWC fp32 activation view: channels [c0, c0+C) of a [B,H,W,ld] device buffer.
+    A channel-concat (dl_models/u_net.py:308) is two Acts over one buffer."""
+    __slots__ = ("base", "B", "H", "W", "C", "ld", "c0", "ptr")
+
+    def __init__(self, base: torch.Tensor, c0: int = 0, C_: int = None):
+        if base.dim() != 4 or not base.is_contiguous() or base.dtype != torch.float32:
+            raise ValueError("Act needs a contiguous fp32 [B,H,W,ld] tensor")
+        self.base = base
+        self.B, self.H, self.W, self.ld = base.shape
+        self.c0 = c0
+        self.C = self.ld - c0 if C_ is None else C_
+        if self.c0 % 4 or self.ld % 4 or self.c0 + self.C > self.ld:
+            raise ValueError("channel offset and pixel stride must be multiples of 4")
+        self.ptr = base.data_ptr() + 4 * c0
+
+    @property
+    def P(self):
+        return self.B * self.H * self.W
+
+    def slice(self, c0, C_):
+        return Act(self.base, self.c0 + c0, C_)
+
+    def dense(self):
+        """A contiguous [B,H,W,C] copy (tests / debugging)."""
+        return self.base[..., self.c0:self.c0 + self.C].contiguous()
+
+
+def new_act(B, H, W, C_, device, ld=None):
+    return Act(torch.empty((B, H, W, C_ if ld is None else ld), dtype=torch.float32, device=device), 0, C_)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if isinstance(t, Act):
+        return C.c_void_p(t.ptr)
+    return C.c_void_p(t.data_ptr())
+
+
+def geom(B, H, W, Cin, Cout, k, stride):
+    return ConvGeom(B, H, W, Cin, Cout, k, stride)
+
+
+class Workspace:
+    """A reusable scratch buffer (the C ABI never allocates)."""
+
+    def __init__(self, device, nbytes=0):
+        self.device = device
+        self.buf = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+
+    def reserve(self, nbytes):
+        if nbytes > self.buf.numel():
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr())
+
+    @property
+    def nbytes(self):
+        return self.buf.numel()
+
+
+# ---- Conv2D / Conv2DTranspose --------------------------------------------------------------
+
+def conv2d_fwd(g, x: Act, w, bias, y: Act, addend: Act = None):
+    """Conv2D(padding='same') forward (dl_models/u_net.py:269-276, :366, :248, :262)."""
+    check(_lib.lib().unetrir_conv2d_fwd_f32(C.byref(g), _p(x), x.ld, _p(w), _p(bias), _p(addend),
+                                            addend.ld if addend is not None else 0, _p(y), y.ld, _stream()),
+          "conv2d_fwd")
+
+
+def conv2d_dgrad(g, dy: Act, wt, dx: Act, addend: Act = None):
+    check(_lib.lib().unetrir_conv2d_dgrad_f32(C.byref(g), _p(dy), dy.ld, _p(wt), _p(addend),
+                                              addend.ld if addend is not None else 0, _p(dx), dx.ld, _stream()),
+          "conv2d_dgrad")
+
+
+def conv2d_wgrad_ws_bytes(g):
+    return _lib.lib().unetrir_conv2d_wgrad_ws_bytes(C.byref(g))
+
+
+def conv2d_wgrad(g, x: Act, dy: Act, dw, ws: Workspace, reg=0.0, w=None):
+    ws.reserve(conv2d_wgrad_ws_bytes(g))
+    check(_lib.lib().unetrir_conv2d_wgrad_f32(C.byref(g), _p(x), x.ld, _p(dy), dy.ld, _p(dw), float(reg), _p(w),
+                                              ws.ptr, ws.nbytes, _stream()), "conv2d_wgrad")
+
+
+def conv2d_transpose_fwd(g, x: Act, wt, bias, y: Act):
+    """Conv2DTranspose(strides=2, padding='same') forward (dl_models/u_net.py:297-304)."""
+    check(_lib.lib().unetrir_conv2d_transpose_fwd_f32(C.byref(g), _p(x), x.ld, _p(wt), _p(bias), _p(y), y.ld,
+                                                      _stream()), "conv2d_transpose_fwd")
+
+
+def conv2d_transpose_dgrad(g, dy: Act, w, dx: Act, addend: Act = None):
+    check(_lib.lib().unetrir_conv2d_transpose_dgrad_f32(C.byref(g), _p(dy), dy.ld, _p(w), _p(addend),
+                                                        addend.ld if addend is not None else 0, _p(dx), dx.ld,
+                                                        _stream()), "conv2d_transpose_dgrad")
+
+
+def conv2d_transpose_wgrad_ws_bytes(g):
+    return _lib.lib().unetrir_conv2d_transpose_wgrad_ws_bytes(C.byref(g))
+
+
+def conv2d_transpose_wgrad(g, x: Act, dy: Act, dw, ws: Workspace, reg=0.0, w=None):
+    ws.reserve(conv2d_transpose_wgrad_ws_bytes(g))
+    check(_lib.lib().unetrir_conv2d_transpose_wgrad_f32(C.byref(g), _p(x), x.ld, _p(dy), dy.ld, _p(dw), float(reg),
+                                                        _p(w), ws.ptr, ws.nbytes, _stream()),
+          "conv2d_transpose_wgrad")
+
+
+def transpose_weight(w, wt, N, T, C_):
+    """[N][T][C] -> [C][T][N]."""
+    check(_lib.lib().unetrir_transpose_weight_f32(_p(w), _p(wt), N, T, C_, _stream()), "transpose_weight")
+
+
+# ---- BatchNormalization + ReLU ---------------------------------------------------------------
+
+def bn_ws_bytes(P, C_):
+    return _lib.lib().unetrir_bn_ws_bytes(P, C_)
+
+
+def bn_stats(x: Act, gamma, beta, affine, saved, ws: Workspace, moving_mean=None, moving_var=None,
+             eps=1e-3, momentum=0.99):
+    """BatchNormalization() batch statistics (dl_models/u_net.py:368)."""
+    ws.reserve(bn_ws_bytes(x.P, x.C))
+    check(_lib.lib().unetrir_bn_stats_f32(_p(x), x.ld, x.P, x.C, _p(gamma), _p(beta), eps, momentum,
+                                          _p(moving_mean), _p(moving_var), _p(affine), _p(saved), ws.ptr, ws.nbytes,
+                                          _stream()), "bn_stats")
+
+
+def bn_apply(x: Act, affine, y: Act, relu=True):
+    check(_lib.lib().unetrir_bn_apply_f32(_p(x), x.ld, x.P, x.C, _p(affine), int(relu), _p(y), y.ld, _stream()),
+          "bn_apply")
+
+
+def bn_bwd(da: Act, x: Act, gamma, affine, saved, dx: Act, dgamma, dbeta, ws: Workspace, relu=True):
+    ws.reserve(bn_ws_bytes(x.P, x.C))
+    check(_lib.lib().unetrir_bn_bwd_f32(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(gamma), _p(affine), _p(saved),
+                                        int(relu), _p(dx), dx.ld, _p(dgamma), _p(dbeta), ws.ptr, ws.nbytes,
+                                        _stream()), "bn_bwd")
+
+
+def colsum(x: Act, out, ws: Workspace):
+    """Bias gradient: out[c] = sum over pixels."""
+    ws.reserve(bn_ws_bytes(x.P, x.C))
+    check(_lib.lib().unetrir_colsum_f32(_p(x), x.ld, x.P, x.C, _p(out), ws.ptr, ws.nbytes, _stream()), "colsum")
+
+
+def relu_fwd(x: Act, y: Act):
+    check(_lib.lib().unetrir_relu_fwd_f32(_p(x), x.ld, x.P, x.C, _p(y), y.ld, _stream()), "relu_fwd")
+
+
+def relu_bwd(da: Act, x: Act, dx: Act):
+    check(_lib.lib().unetrir_relu_bwd_f32(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(dx), dx.ld, _stream()),
+          "relu_bwd")
+
+
+# ---- boundary / head / loss ------------------------------------------------------------------
+
+def nchw_to_nhwc_pad(x, y: Act):
+    B, C_, H, W = x.shape
+    check(_lib.lib().unetrir_nchw_to_nhwc_pad_f32(_p(x), B, C_, H, W, _p(y), y.ld, _stream()), "nchw_to_nhwc_pad")
+
+
+def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_out, ws: Workspace):
+    """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits."""
+    B, _, H, W = target.shape
+    ws.reserve(_lib.lib().unetrir_loss_ws_bytes(B * H * W))
+    check(_lib.lib().unetrir_sigmoid_loss_f32(_p(logits), logits.ld, _p(target), B, H, W, alpha, inv_norm, _p(pred),
+                                              _p(dlogits), _p(loss_out), ws.ptr, ws.nbytes, _stream()),
+          "sigmoid_loss")
+
+
+def sigmoid_nchw(logits: Act, pred):
+    B, _, H, W = pred.shape
+    check(_lib.lib().unetrir_sigmoid_nchw_f32(_p(logits), logits.ld, B, H, W, _p(pred), _stream()), "sigmoid_nchw")
+
+
+def sigmoid_bwd(pred, dpred, dlogits: Act):
+    B, _, H, W = pred.shape
+    check(_lib.lib().unetrir_sigmoid_bwd_f32(_p(pred), _p(dpred), B, H, W, _p(dlogits), _stream()), "sigmoid_bwd")
+
+
+# ---- information vector ----------------------------------------------------------------------
+
+def embedding_fwd(idx, table, out):
+    check(_lib.lib().unetrir_embedding_fwd_f32(_p(idx), idx.numel(), _p(table), table.shape[0], table.shape[1],
+                                               _p(out), _stream()), "embedding_fwd")
+
+
+def embedding_bwd(idx, dout, dtable):
+    check(_lib.lib().unetrir_embedding_bwd_f32(_p(idx), idx.numel(), _p(dout), dtable.shape[0], dtable.shape[1],
+                                               _p(dtable), _stream()), "embedding_bwd")
+
+
+def mul(x, m, y):
+    check(_lib.lib().unetrir_mul_f32(_p(x), _p(m), _p(y), x.numel(), _stream()), "mul")
+
+
+def sumsq(x, coef, out, accumulate, ws: Workspace):
+    ws.reserve(512 * 8)
+    check(_lib.lib().unetrir_sumsq_f32(_p(x), x.numel(), float(coef), _p(out), int(accumulate), ws.ptr, ws.nbytes,
+                                       _stream()), "sumsq")
+
+
+def adam(theta, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    """tf.keras.optimizers.Adam step over a flat buffer (main_training.py:168-169, :268)."""
+    check(_lib.lib().unetrir_adam_f32(_p(theta), _p(g), _p(m), _p(v), theta.numel(), float(lr_t), beta1, beta2, eps,
+                                      float(grad_scale), _stream()), "adam")
+
+
+# ---- profiling hooks -------------------------------------------------------------------------
+
+def prof_enable(on):
+    _lib.lib().unetrir_prof_enable(int(on))
+
+
+def prof_collect():
+    n = _lib.PROF_FAMILIES
+    counts = (C.c_int * n)()
+    ms = (C.c_double * n)()
+    fl = (C.c_double * n)()
+    _lib.lib().unetrir_prof_collect(counts, ms, fl)
+    return list(counts), list(ms), list(fl)
