@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py - RIR spectrograms/sec for one full U-Net train step (forward + loss + backward + gradient
+all-reduce + Adam) on N MI355X GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload at every N: BASELINE.json configs[1] per GPU - dl_models/u_net.py UNet, 4 down / 4 up, number_filters_0=64,
+kernels=3, batch 32 of [2,256,256] synthetic amp/phase spectrograms + [2,16] information vectors (weak scaling: the
+global batch is 32*N, configs[2] at N=8).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def synthetic_batch(B, H, W, device, seed):
+    """Device-side synthetic inputs with the contract of DataGenerator.__getitem__ (datageneratorv2.py:64-102):
+    amp/phase ~ U[0,1) with the zero-padded border of TensorPadder (129/144 rows, 151/160 cols), emb in [26,1282)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    spec_in = torch.rand((B, 2, H, W), device=device, generator=g)
+    spec_out = torch.rand((B, 2, H, W), device=device, generator=g)
+    r0, c0 = -(-896 * H // 1000), -(-944 * W // 1000)
+    for a in (spec_in, spec_out):
+        a[:, :, r0:, :] = 0.0
+        a[:, :, :, c0:] = 0.0
+    emb = torch.randint(26, 1282, (B, 2, 16), device=device, generator=g, dtype=torch.int64)
+    return spec_in.contiguous(), emb, spec_out.contiguous()
+
+
+def cpu_baseline(F0, H, W, budget_s=25.0):
+    """The CPU restatement of the same train step (oracle/torch_ref.py, stock torch CPU ops) on this box's host cores,
+    on a bounded sample: the same model at batch 4, a few steps."""
+    from oracle import torch_ref as R
+    B = 4
+    cfg = R.Config(H, W, F0, 3)
+    params = R.init_params(cfg)
+    st = R.TrainState(cfg, params, lr=5e-7)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
+    spec_in, spec_out, emb = torch.tensor(spec_in), torch.tensor(spec_out), torch.tensor(emb)
+    t0 = time.time()
+    st.step(spec_in, emb, spec_out)               # warm-up
+    warm = time.time() - t0
+    times = []
+    while (not times) or (sum(times) + warm + (sum(times) / len(times)) < budget_s and len(times) < 5):
+        t0 = time.time()
+        st.step(spec_in, emb, spec_out)
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "spectrograms/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"same model (F0={F0}, {H}x{W}) at batch {B}, median of {len(times)} steps after 1 warm-up, "
+                      f"oracle/torch_ref.py on torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--f0", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event bracketing of conv kernels")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import unet_rir_amd as U
+    H = W = args.size
+    eng = U.UNetEngine(H, W, args.batch, F0=args.f0, k=3, depth=args.depth, device=device, n_replicas=world)
+    gen = torch.Generator()
+    gen.manual_seed(0)                                   # identical initial variables on every replica
+    eng.reset_parameters(gen)
+    tr = U.Trainer(eng, lr=5e-7, alpha=0.9, world_size=world, bucket_bytes=args.bucket_mb << 20, dropout=True)
+    tr.broadcast_parameters(0)
+    spec_in, emb, spec_out = synthetic_batch(args.batch, H, W, device, 1234 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step(spec_in, emb, spec_out)
+    sync()
+    prof = (not args.no_prof) and rank == 0
+    if prof:
+        U.ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(spec_in, emb, spec_out)
+    sync()
+    dt = time.perf_counter() - t0
+    fam = None
+    if prof:
+        fam = U.ops.prof_collect()
+        U.ops.prof_enable(False)
+    loss = tr.last_loss()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    global_batch = args.batch * world
+    ms = dt * 1e3 / args.steps
+    out = {
+        "metric": "RIR spectrograms/sec (train step) on [B,2,256,256] U-Net",
+        "value": global_batch * args.steps / dt,
+        "unit": "spectrograms/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"UNet 4 down/4 up, number_filters_0={args.f0}, kernels=3, per-GPU batch {args.batch} of "
+                               f"[2,{H},{W}] + [2,16] (BASELINE.json configs[1] per GPU; global batch {global_batch}), "
+                               "full train step: fwd + loss + bwd + grad all-reduce + Adam",
+                   "global_batch": global_batch, "parallelism": f"dp{world}", "params": eng.n_params()},
+        "loss": loss,
+    }
+    if fam is not None:
+        counts, fms, ffl = fam
+        conv_ms = sum(fms[0:3])
+        conv_fl = sum(ffl[0:3])
+        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "igemm_fwd_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv: fwd, dgrad, wgrad; layers with "
+                      "Cin,Cout >= 8)",
+            "launches_per_step": sum(counts[0:3]) / args.steps,
+            "avg_launch_ms": conv_ms / max(sum(counts[0:3]), 1),
+            "algorithmic_gflop_per_step": conv_fl / args.steps / 1e9,
+            "conv_ms_per_step": conv_ms / args.steps,
+            "by_family": {name: {"launches": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
+                          for i, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad"), (5, "stem_head"))},
+        }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.f0, H, W)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

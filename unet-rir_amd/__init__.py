@@ -5,5 +5,8 @@ device memory, streams and torch.distributed only.
 """
 from . import _lib, build, ops  # noqa: F401
 from ._lib import UnetrirError  # noqa: F401
+from .engine import UNetEngine  # noqa: F401
+from .model import UNet  # noqa: F401
+from .trainer import GradBucketer, Trainer, lr_schedule  # noqa: F401
 
-__all__ = ["ops", "build", "UnetrirError"]
+__all__ = ["ops", "build", "UnetrirError", "UNetEngine", "UNet", "Trainer", "GradBucketer", "lr_schedule"]

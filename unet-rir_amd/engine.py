@@ -1,0 +1,504 @@
+"""Execution plan of the U-Net train step on one MI355X: buffers, forward schedule, backward
+schedule.  Mirrors the Keras graph UNet._build creates (dl_models/u_net.py:201-251, mode 0) and
+the tape.gradient pass of main_training.py:256-267, as an explicit list of HIP kernel launches.
+
+Memory layout in HBM (all fp32):
+  * activations NHWC, one buffer per layer output, allocated once for a fixed batch size;
+    the skip concat of level l is ONE buffer [B,Hl,Wl,2*Cl]: the encoder's BN+ReLU output is written
+    into channels [0,Cl), the Conv2DTranspose output into [Cl,2Cl) (dl_models/u_net.py:308 costs no copy);
+  * parameters, gradients and Adam moments are four flat buffers with identical layout, ordered by
+    backward completion (head first, enc1 last) so gradient buckets for the all-reduce are contiguous
+    slices that become final in order;
+  * Conv2D kernels [Cout][k][k][Cin], Conv2DTranspose kernels [Cin][k][k][Cout], Dense [out][in];
+    the first conv's Cin and the head's Cout are zero-padded 2 -> 4 (pad weights stay exactly zero:
+    their gradient is identically zero).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .ops import Act
+
+BN_EPS = 1e-3          # keras BatchNormalization default (dl_models/u_net.py:368)
+BN_MOMENTUM = 0.99
+L2_COEF = 1e-3         # l2(0.001) on strided Conv2D / Conv2DTranspose kernels (dl_models/u_net.py:274, :302)
+VOCAB, EMB_DIM, VEC_CH = 2000, 256, 16   # dl_models/u_net.py:255-257
+DROPOUT_P = 0.3        # dl_models/u_net.py:260
+ALIGN = 64             # parameter offsets are multiples of 64 floats (256 B)
+
+
+def same_out(n, s):
+    return -(-n // s)
+
+
+class ParamSpec:
+    __slots__ = ("name", "shape", "offset", "numel", "kind", "keras_shape")
+
+    def __init__(self, name, shape, kind, keras_shape):
+        self.name, self.shape, self.kind, self.keras_shape = name, tuple(shape), kind, tuple(keras_shape)
+        self.numel = int(math.prod(shape))
+        self.offset = -1
+
+
+class UNetEngine:
+    """One replica of the model for a fixed per-replica batch size B on one device."""
+
+    def __init__(self, H, W, B, F0=32, k=3, depth=4, batchnorm=True, inf_vector_shape=(2, 16), s0=1, s=2,
+                 device="cuda:0", n_replicas=1):
+        if s0 != 1 or s != 2:
+            raise NotImplementedError("HIP path implements resize_factor_0=[1,1], res_factor=[2,2] (the reference defaults)")
+        if F0 % 4:
+            raise ValueError("number_filters_0 must be a multiple of 4")
+        if k < 1 or k > 6:
+            raise ValueError("kernels must be in 1..6")
+        self.H, self.W, self.B, self.F0, self.k, self.depth = H, W, B, F0, k, depth
+        self.batchnorm = batchnorm
+        self.inf_vector_shape = tuple(inf_vector_shape)
+        self.device = torch.device(device)
+        self.n_replicas = n_replicas
+        self.L = depth + 1
+        self.ch = [F0 * 2 ** l for l in range(self.L)]
+        self.hw = [(H, W)]
+        for _ in range(depth):
+            h, w = self.hw[-1]
+            self.hw.append((same_out(h, 2), same_out(w, 2)))
+        for l in range(depth):
+            if self.hw[l][0] != 2 * self.hw[l + 1][0] or self.hw[l][1] != 2 * self.hw[l + 1][1]:
+                raise ValueError("spatial size must halve exactly at every level that feeds a skip concat")
+        self.h5, self.w5 = self.hw[-1]
+        self.n_idx = int(math.prod(self.inf_vector_shape))
+        self.vec_in = self.n_idx * EMB_DIM
+        self.vec_dim = self.h5 * self.w5 * VEC_CH
+        self._build_params()
+        self._alloc()
+        self.ws = ops.Workspace(self.device)
+        self._reserve_workspace()
+        self.training = True
+        self.t_dirty = True
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self):
+        k, ch, L = self.k, self.ch, self.L
+        specs = []
+
+        def add(name, shape, kind, keras_shape):
+            specs.append(ParamSpec(name, shape, kind, keras_shape))
+
+        def bn(prefix, c):
+            if self.batchnorm:
+                add(prefix + ".gamma", (c,), "gamma", (c,))
+                add(prefix + ".beta", (c,), "beta", (c,))
+
+        # backward completion order: head, dec1..decD, vec, encL..enc1
+        add("head.kernel", (4, 6, 6, ch[0]), "conv_padout", (6, 6, ch[0], 2))
+        add("head.bias", (4,), "bias_pad", (2,))
+        for l in range(1, self.depth + 1):
+            c = ch[l - 1]
+            add(f"dec{l}.cb1b.kernel", (c, 3, 3, c), "conv", (3, 3, c, c))
+            add(f"dec{l}.cb1b.bias", (c,), "bias", (c,))
+            bn(f"dec{l}.cb1b", c)
+            add(f"dec{l}.cb1a.kernel", (c, k, k, 2 * c), "conv", (k, k, 2 * c, c))
+            add(f"dec{l}.cb1a.bias", (c,), "bias", (c,))
+            bn(f"dec{l}.cb1a", c)
+            add(f"dec{l}.up.kernel", (ch[l], k, k, c), "convT", (k, k, c, ch[l]))
+            add(f"dec{l}.up.bias", (c,), "bias", (c,))
+        add("vec.conv.kernel", (ch[-1], 1, 1, VEC_CH), "conv", (1, 1, VEC_CH, ch[-1]))
+        add("vec.conv.bias", (ch[-1],), "bias", (ch[-1],))
+        add("vec.dense.kernel", (self.vec_dim, self.vec_in), "dense", (self.vec_in, self.vec_dim))
+        add("vec.dense.bias", (self.vec_dim,), "bias", (self.vec_dim,))
+        add("vec.embedding", (VOCAB, EMB_DIM), "embedding", (VOCAB, EMB_DIM))
+        for l in range(L, 0, -1):
+            c = ch[l - 1]
+            cin = ch[l - 2] if l > 1 else 2
+            add(f"enc{l}.cb1.kernel", (c, 3, 3, c), "conv", (3, 3, c, c))
+            add(f"enc{l}.cb1.bias", (c,), "bias", (c,))
+            bn(f"enc{l}.cb1", c)
+            if l > 1:
+                add(f"enc{l}.down.kernel", (c, k, k, cin), "conv", (k, k, cin, c))
+            else:
+                add(f"enc{l}.down.kernel", (c, k, k, 4), "conv_padin", (k, k, 2, c))
+            add(f"enc{l}.down.bias", (c,), "bias", (c,))
+        off = 0
+        for s_ in specs:
+            s_.offset = off
+            off += -(-s_.numel // ALIGN) * ALIGN
+        self.specs = OrderedDict((s_.name, s_) for s_ in specs)
+        self.n_flat = off
+        dev = self.device
+        self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_t = 0
+        self.p = {n: self.theta[s_.offset:s_.offset + s_.numel].view(s_.shape) for n, s_ in self.specs.items()}
+        self.g = {n: self.grad[s_.offset:s_.offset + s_.numel].view(s_.shape) for n, s_ in self.specs.items()}
+        # transposed work copies: Conv2D kernels for their data gradient, Conv2DTranspose kernels for their forward
+        toff, self.tspec = 0, {}
+        for n, s_ in self.specs.items():
+            if s_.kind in ("conv", "convT", "dense", "conv_padout"):
+                self.tspec[n] = toff
+                toff += -(-s_.numel // ALIGN) * ALIGN
+        self.theta_t = torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
+        self.pt = {n: self.theta_t[o:o + self.specs[n].numel] for n, o in self.tspec.items()}
+        # BatchNorm moving statistics (non-trainable)
+        self.bn_names = [n[:-len(".gamma")] for n in self.specs if n.endswith(".gamma")]
+        self.moving = {}
+        for b in self.bn_names:
+            c = self.specs[b + ".gamma"].numel
+            self.moving[b + ".moving_mean"] = torch.zeros(c, dtype=torch.float32, device=dev)
+            self.moving[b + ".moving_variance"] = torch.ones(c, dtype=torch.float32, device=dev)
+        self.l2_names = [f"enc{l}.down.kernel" for l in range(1, L + 1)] + [f"dec{l}.up.kernel" for l in range(1, self.depth + 1)]
+
+    def reset_parameters(self, generator=None):
+        """Keras default initialisers (no initialiser argument anywhere in dl_models/u_net.py): glorot_uniform
+        kernels, zero biases, gamma 1, beta 0, Embedding U(-0.05, 0.05)."""
+        with torch.no_grad():
+            for n, s_ in self.specs.items():
+                t = self.p[n]
+                ks = s_.keras_shape
+                if s_.kind == "embedding":
+                    t.copy_((torch.rand(s_.shape, generator=generator) * 0.1 - 0.05).to(self.device))
+                elif s_.kind in ("conv", "convT", "conv_padin", "conv_padout", "dense"):
+                    if len(ks) == 4:
+                        rf = ks[0] * ks[1]
+                        fan_in, fan_out = ks[2] * rf, ks[3] * rf
+                    else:
+                        fan_in, fan_out = ks
+                    lim = math.sqrt(6.0 / (fan_in + fan_out))
+                    w = ((torch.rand(s_.shape, generator=generator) * 2 - 1) * lim).to(self.device)
+                    if s_.kind == "conv_padin":
+                        w[..., 2:] = 0
+                    if s_.kind == "conv_padout":
+                        w[2:] = 0
+                    t.copy_(w)
+                elif s_.kind == "gamma":
+                    t.fill_(1.0)
+                else:
+                    t.zero_()
+            for n, b in self.moving.items():
+                b.fill_(1.0 if n.endswith("variance") else 0.0)
+            self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t = 0
+        self.t_dirty = True
+
+    # ---- conversion to / from the reference's own (Keras) layouts -----------------------------
+    def load_keras_params(self, params):
+        """params: name -> array in Keras layout (HWIO Conv2D, HWOI Conv2DTranspose, [in,out] Dense)."""
+        with torch.no_grad():
+            for n, s_ in self.specs.items():
+                a = torch.as_tensor(params[n]).to(torch.float32)
+                if tuple(a.shape) != s_.keras_shape:
+                    raise ValueError(f"{n}: expected Keras shape {s_.keras_shape}, got {tuple(a.shape)}")
+                t = self.p[n]
+                if s_.kind in ("conv", "convT"):
+                    t.copy_(a.permute(3, 0, 1, 2).to(self.device))
+                elif s_.kind == "conv_padin":
+                    t.zero_(); t[..., :2].copy_(a.permute(3, 0, 1, 2).to(self.device))
+                elif s_.kind == "conv_padout":
+                    t.zero_(); t[:2].copy_(a.permute(3, 0, 1, 2).to(self.device))
+                elif s_.kind == "dense":
+                    t.copy_(a.t().to(self.device))
+                elif s_.kind == "bias_pad":
+                    t.zero_(); t[:2].copy_(a.to(self.device))
+                else:
+                    t.copy_(a.to(self.device))
+        self.t_dirty = True
+
+    def _to_keras(self, views):
+        out = {}
+        for n, s_ in self.specs.items():
+            t = views[n].detach()
+            if s_.kind in ("conv", "convT"):
+                a = t.permute(1, 2, 3, 0)
+            elif s_.kind == "conv_padin":
+                a = t[..., :2].permute(1, 2, 3, 0)
+            elif s_.kind == "conv_padout":
+                a = t[:2].permute(1, 2, 3, 0)
+            elif s_.kind == "dense":
+                a = t.t()
+            elif s_.kind == "bias_pad":
+                a = t[:2]
+            else:
+                a = t
+            out[n] = a.contiguous().cpu()
+        return out
+
+    def export_keras_params(self):
+        return self._to_keras(self.p)
+
+    def export_keras_grads(self):
+        return self._to_keras(self.g)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc(self):
+        B, dev, ch, hw, D = self.B, self.device, self.ch, self.hw, self.depth
+        A = lambda h, w, c: ops.new_act(B, h, w, c, dev)
+        self.x4, self.down, self.y, self.a = A(self.H, self.W, 4), {}, {}, {}
+        self.cat, self.g_cat = {}, {}
+        self.g_down, self.g_y = {}, {}
+        for l in range(1, self.L + 1):
+            h, w = hw[l - 1]
+            c = ch[l - 1]
+            self.down[l], self.y[l] = A(h, w, c), A(h, w, c)
+            self.g_down[l], self.g_y[l] = A(h, w, c), A(h, w, c)
+            if l <= D:
+                self.cat[l], self.g_cat[l] = A(h, w, 2 * c), A(h, w, 2 * c)
+                self.a[l] = self.cat[l].slice(0, c)
+            else:
+                self.a[l] = A(h, w, c)
+        cL = ch[-1]
+        self.emb_out = torch.empty((B * self.n_idx, EMB_DIM), dtype=torch.float32, device=dev)
+        self.g_emb_out = torch.empty_like(self.emb_out)
+        self.flat = Act(self.emb_out.view(B, 1, 1, self.vec_in))
+        self.g_flat = Act(self.g_emb_out.view(B, 1, 1, self.vec_in))
+        self.v = ops.new_act(B, 1, 1, self.vec_dim, dev)
+        self.vd = ops.new_act(B, 1, 1, self.vec_dim, dev)
+        self.g_v = ops.new_act(B, 1, 1, self.vec_dim, dev)
+        self.g_vd = ops.new_act(B, 1, 1, self.vec_dim, dev)
+        self.vd_sp = Act(self.vd.base.view(B, self.h5, self.w5, VEC_CH))       # Reshape((h5,w5,16)) is NHWC
+        self.g_vd_sp = Act(self.g_vd.base.view(B, self.h5, self.w5, VEC_CH))
+        self.z, self.g_z = A(self.h5, self.w5, cL), A(self.h5, self.w5, cL)
+        self.ya, self.aa, self.yb, self.ab = {}, {}, {}, {}
+        self.g_ya, self.g_aa, self.g_yb, self.g_ab = {}, {}, {}, {}
+        for l in range(1, D + 1):
+            h, w = hw[l - 1]
+            c = ch[l - 1]
+            for d_ in (self.ya, self.aa, self.yb, self.ab, self.g_ya, self.g_aa, self.g_yb, self.g_ab):
+                d_[l] = A(h, w, c)
+        self.logits, self.g_logits = A(self.H, self.W, 4), A(self.H, self.W, 4)
+        self.pred = torch.empty((B, 2, self.H, self.W), dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.reg_out = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.bn_affine = {b: torch.empty(2 * self.specs[b + ".gamma"].numel, dtype=torch.float32, device=dev) for b in self.bn_names}
+        self.bn_saved = {b: torch.empty(2 * self.specs[b + ".gamma"].numel, dtype=torch.float32, device=dev) for b in self.bn_names}
+        self.dropout_mask = None
+        self.emb_idx = torch.zeros(B * self.n_idx, dtype=torch.int32, device=dev)
+        # geometry descriptors
+        G, k = ops.geom, self.k
+        self.geo = {}
+        for l in range(1, self.L + 1):
+            h, w = hw[l - 1]
+            c = ch[l - 1]
+            if l == 1:
+                self.geo["enc1.down"] = G(B, h, w, 4, c, k, 1)
+            else:
+                hi, wi = hw[l - 2]
+                self.geo[f"enc{l}.down"] = G(B, hi, wi, ch[l - 2], c, k, 2)
+            self.geo[f"enc{l}.cb1"] = G(B, h, w, c, c, 3, 1)
+        self.geo["vec.dense"] = G(B, 1, 1, self.vec_in, self.vec_dim, 1, 1)
+        self.geo["vec.conv"] = G(B, self.h5, self.w5, VEC_CH, cL, 1, 1)
+        for l in range(1, D + 1):
+            h, w = hw[l - 1]
+            c = ch[l - 1]
+            hl, wl = hw[l]
+            self.geo[f"dec{l}.up"] = G(B, hl, wl, ch[l], c, k, 2)
+            self.geo[f"dec{l}.cb1a"] = G(B, h, w, 2 * c, c, k, 1)
+            self.geo[f"dec{l}.cb1b"] = G(B, h, w, c, c, 3, 1)
+        self.geo["head"] = G(B, self.H, self.W, ch[0], 4, 6, 1)
+
+    def _reserve_workspace(self):
+        need = 1 << 16
+        for n, g in self.geo.items():
+            if n.endswith(".up"):
+                need = max(need, ops.conv2d_transpose_wgrad_ws_bytes(g))
+            else:
+                need = max(need, ops.conv2d_wgrad_ws_bytes(g))
+        P0 = self.B * self.H * self.W
+        need = max(need, ops.bn_ws_bytes(P0, max(self.ch[0], 4)), ops.bn_ws_bytes(self.B * self.h5 * self.w5, self.ch[-1]),
+                   ops.bn_ws_bytes(self.B, self.vec_dim))
+        for l in range(1, self.L + 1):
+            h, w = self.hw[l - 1]
+            need = max(need, ops.bn_ws_bytes(self.B * h * w, 2 * self.ch[l - 1]))
+        self.ws.reserve(need)
+
+    # ------------------------------------------------------------------ helpers
+    def refresh_transposed(self):
+        """Conv2D kernels -> [Cin][T][Cout] for dgrad; Conv2DTranspose kernels -> [Cout][T][Cin] for forward."""
+        for n in self.tspec:
+            s_ = self.specs[n]
+            N = s_.shape[0]
+            if s_.kind == "dense":
+                T, C_ = 1, s_.shape[1]
+            else:
+                T, C_ = s_.shape[1] * s_.shape[2], s_.shape[3]
+            ops.transpose_weight(self.p[n], self.pt[n], N, T, C_)
+        self.t_dirty = False
+
+    def _bn_relu_fwd(self, name, y: Act, out: Act):
+        if self.batchnorm:
+            if self.training:
+                ops.bn_stats(y, self.p[name + ".gamma"], self.p[name + ".beta"], self.bn_affine[name], self.bn_saved[name],
+                             self.ws, self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"],
+                             BN_EPS, BN_MOMENTUM)
+            else:
+                c = y.C
+                rstd = torch.rsqrt(self.moving[name + ".moving_variance"] + BN_EPS)
+                scale = self.p[name + ".gamma"] * rstd
+                self.bn_affine[name][:c] = scale
+                self.bn_affine[name][c:] = self.p[name + ".beta"] - self.moving[name + ".moving_mean"] * scale
+            ops.bn_apply(y, self.bn_affine[name], out, relu=True)
+        else:
+            ops.relu_fwd(y, out)
+
+    def _bn_relu_bwd(self, name, da: Act, y: Act, dy: Act):
+        if self.batchnorm:
+            ops.bn_bwd(da, y, self.p[name + ".gamma"], self.bn_affine[name], self.bn_saved[name], dy,
+                       self.g[name + ".gamma"], self.g[name + ".beta"], self.ws, relu=True)
+        else:
+            ops.relu_bwd(da, y, dy)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, spec, emb, dropout_mask=None, target=None, global_batch=None, alpha=0.9):
+        """spec f32 [B,2,H,W] NCHW, emb int [B,2,16].  With `target` also evaluates compute_loss
+        (main_training.py:203-235) and seeds the backward pass.  Returns the NCHW prediction buffer."""
+        B, D, p = self.B, self.depth, self.p
+        if tuple(spec.shape) != (B, 2, self.H, self.W) or spec.dtype != torch.float32 or not spec.is_contiguous():
+            raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor, got {tuple(spec.shape)} {spec.dtype}")
+        if tuple(emb.shape) != (B,) + self.inf_vector_shape:
+            raise ValueError(f"emb must be [{B},{self.inf_vector_shape}]")
+        if spec.device != self.device:
+            raise ValueError("inputs must live on the engine's device")
+        if self.t_dirty or self.training:
+            self.refresh_transposed()
+        self.emb_idx.copy_(emb.reshape(-1).to(torch.int32))
+        ops.nchw_to_nhwc_pad(spec, self.x4)
+        prev = self.x4
+        for l in range(1, self.L + 1):
+            ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, p[f"enc{l}.down.kernel"], p[f"enc{l}.down.bias"], self.down[l])
+            ops.conv2d_fwd(self.geo[f"enc{l}.cb1"], self.down[l], p[f"enc{l}.cb1.kernel"], p[f"enc{l}.cb1.bias"], self.y[l])
+            self._bn_relu_fwd(f"enc{l}.cb1", self.y[l], self.a[l])
+            prev = self.a[l]
+        # information vector branch (dl_models/u_net.py:253-263) + Add (:229)
+        ops.embedding_fwd(self.emb_idx, p["vec.embedding"], self.emb_out)
+        ops.conv2d_fwd(self.geo["vec.dense"], self.flat, p["vec.dense.kernel"], p["vec.dense.bias"], self.v)
+        self.dropout_mask = dropout_mask
+        if dropout_mask is not None:
+            ops.mul(self.v.base, dropout_mask, self.vd.base)
+            vsp = self.vd_sp
+        else:
+            vsp = Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
+        ops.conv2d_fwd(self.geo["vec.conv"], vsp, p["vec.conv.kernel"], p["vec.conv.bias"], self.z, addend=self.a[self.L])
+        cur = self.z
+        for l in range(D, 0, -1):
+            c = self.ch[l - 1]
+            ops.conv2d_transpose_fwd(self.geo[f"dec{l}.up"], cur, self.pt[f"dec{l}.up.kernel"], p[f"dec{l}.up.bias"],
+                                     self.cat[l].slice(c, c))
+            ops.conv2d_fwd(self.geo[f"dec{l}.cb1a"], self.cat[l], p[f"dec{l}.cb1a.kernel"], p[f"dec{l}.cb1a.bias"], self.ya[l])
+            self._bn_relu_fwd(f"dec{l}.cb1a", self.ya[l], self.aa[l])
+            ops.conv2d_fwd(self.geo[f"dec{l}.cb1b"], self.aa[l], p[f"dec{l}.cb1b.kernel"], p[f"dec{l}.cb1b.bias"], self.yb[l])
+            self._bn_relu_fwd(f"dec{l}.cb1b", self.yb[l], self.ab[l])
+            cur = self.ab[l]
+        ops.conv2d_fwd(self.geo["head"], cur, p["head.kernel"], p["head.bias"], self.logits)
+        if target is not None:
+            gb = B if global_batch is None else global_batch
+            inv_norm = 1.0 / (2.0 * self.H * self.W * gb)
+            ops.sigmoid_loss(self.logits, target, alpha, inv_norm, self.pred, self.g_logits, self.loss_out, self.ws)
+        else:
+            ops.sigmoid_nchw(self.logits, self.pred)
+        return self.pred
+
+    def reg_loss(self):
+        """sum(model.losses) / replicas (main_training.py:232-233), evaluated on device into reg_out[0]."""
+        first = True
+        for n in self.l2_names:
+            s_ = self.specs[n]
+            ops.sumsq(self.theta[s_.offset:s_.offset + s_.numel], L2_COEF / self.n_replicas, self.reg_out, not first, self.ws)
+            first = False
+        return self.reg_out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dpred=None, on_ready=None, include_reg=True):
+        """Gradients of every trainable variable into the flat gradient buffer.  Seeds from the loss kernel's
+        dL/dlogits (forward(target=...)) or from an upstream dL/dpred (NCHW).  `on_ready(offset_end)` is called
+        after the launches that finalise the gradient range [0, offset_end) of the flat buffer have been enqueued."""
+        D, p, pt, g, ws = self.depth, self.p, self.pt, self.g, self.ws
+        # d/dw of (l2(0.001) * sum w^2) / replicas, folded into the split-K reduction of the weight gradient
+        reg = 2.0 * L2_COEF / self.n_replicas if include_reg else 0.0
+        if dpred is not None:
+            ops.sigmoid_bwd(self.pred, dpred, self.g_logits)
+
+        def ready(name):
+            if on_ready is not None:
+                s_ = self.specs[name]
+                on_ready(s_.offset + (-(-s_.numel // ALIGN) * ALIGN))
+
+        gl = self.g_logits
+        ops.conv2d_wgrad(self.geo["head"], self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws)
+        ops.colsum(gl, g["head.bias"], ws)
+        ready("head.bias")
+        top = self.ab[1] if D >= 1 else self.a[1]
+        g_cur = self.g_ab[1] if D >= 1 else self.g_z
+        ops.conv2d_dgrad(self.geo["head"], gl, pt["head.kernel"], g_cur)
+        for l in range(1, D + 1):
+            c = self.ch[l - 1]
+            # cb1b
+            self._bn_relu_bwd(f"dec{l}.cb1b", self.g_ab[l], self.yb[l], self.g_yb[l])
+            ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws)
+            ops.colsum(self.g_yb[l], g[f"dec{l}.cb1b.bias"], ws)
+            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1b"], self.g_yb[l], pt[f"dec{l}.cb1b.kernel"], self.g_aa[l])
+            # cb1a
+            self._bn_relu_bwd(f"dec{l}.cb1a", self.g_aa[l], self.ya[l], self.g_ya[l])
+            ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws)
+            ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws)
+            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1a"], self.g_ya[l], pt[f"dec{l}.cb1a.kernel"], self.g_cat[l])
+            # Conv2DTranspose
+            g_up = self.g_cat[l].slice(c, c)
+            x_in = self.ab[l + 1] if l < D else self.z
+            g_in = self.g_ab[l + 1] if l < D else self.g_z
+            ops.conv2d_transpose_wgrad(self.geo[f"dec{l}.up"], x_in, g_up, g[f"dec{l}.up.kernel"], ws, reg=reg,
+                                       w=p[f"dec{l}.up.kernel"])
+            ops.colsum(g_up, g[f"dec{l}.up.bias"], ws)
+            ready(f"dec{l}.up.bias")
+            ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, p[f"dec{l}.up.kernel"], g_in)
+        # bottleneck: z = a_L + conv1x1(dropout(dense(embedding)))
+        gz = self.g_z
+        B = self.B
+        has_do = self.dropout_mask is not None
+        vsp = self.vd_sp if has_do else Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
+        ops.conv2d_wgrad(self.geo["vec.conv"], vsp, gz, g["vec.conv.kernel"], ws)
+        ops.colsum(gz, g["vec.conv.bias"], ws)
+        ops.conv2d_dgrad(self.geo["vec.conv"], gz, pt["vec.conv.kernel"], self.g_vd_sp)
+        if has_do:
+            ops.mul(self.g_vd.base, self.dropout_mask, self.g_v.base)
+            gv = self.g_v
+        else:
+            gv = self.g_vd
+        ops.conv2d_wgrad(self.geo["vec.dense"], self.flat, gv, g["vec.dense.kernel"], ws)
+        ops.colsum(gv, g["vec.dense.bias"], ws)
+        ops.conv2d_dgrad(self.geo["vec.dense"], gv, pt["vec.dense.kernel"], self.g_flat)
+        ops.embedding_bwd(self.emb_idx, self.g_emb_out, g["vec.embedding"])
+        ready("vec.embedding")
+        # encoder, deepest level first; the gradient of a_l is (skip half of g_cat_l) + dgrad of the next strided conv
+        g_a = gz
+        for l in range(self.L, 0, -1):
+            self._bn_relu_bwd(f"enc{l}.cb1", g_a, self.y[l], self.g_y[l])
+            ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws)
+            ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws)
+            ops.conv2d_dgrad(self.geo[f"enc{l}.cb1"], self.g_y[l], pt[f"enc{l}.cb1.kernel"], self.g_down[l])
+            x_in = self.a[l - 1] if l > 1 else self.x4
+            ops.conv2d_wgrad(self.geo[f"enc{l}.down"], x_in, self.g_down[l], g[f"enc{l}.down.kernel"], ws, reg=reg,
+                             w=p[f"enc{l}.down.kernel"])
+            ops.colsum(self.g_down[l], g[f"enc{l}.down.bias"], ws)
+            ready(f"enc{l}.down.bias")
+            if l > 1:
+                skip = self.g_cat[l - 1].slice(0, self.ch[l - 2])
+                ops.conv2d_dgrad(self.geo[f"enc{l}.down"], self.g_down[l], pt[f"enc{l}.down.kernel"], skip, addend=skip)
+                g_a = skip
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """tf.keras Adam over the whole flat parameter buffer in one launch (main_training.py:268)."""
+        self.adam_t += 1
+        t = self.adam_t
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        ops.adam(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps, grad_scale)
+        self.t_dirty = True
+
+    def make_dropout_mask(self, generator=None):
+        keep = (torch.rand((self.B, self.vec_dim), device=self.device, generator=generator) >= DROPOUT_P)
+        return keep.to(torch.float32) / (1.0 - DROPOUT_P)
+
+    def n_params(self):
+        """Trainable parameter count in the reference's sense (padding excluded)."""
+        return sum(int(math.prod(s_.keras_shape)) for s_ in self.specs.values())

@@ -1,0 +1,121 @@
+"""Train step and data parallelism.
+
+``Trainer.step`` is the counterpart of ``train_step`` in main_training.py:253-290 (and of the legacy
+``Trainer.step`` of trainer.py:133-144): forward, compute_loss, gradients of every trainable variable, gradient
+all-reduce across replicas, Adam apply.  Data parallelism follows tf.distribute.MirroredStrategy
+(main_training.py:56, :114-117, :323-327): one process per GPU, the global batch is split evenly, every replica
+holds the full model, BatchNorm statistics stay per replica, the loss is normalised by the GLOBAL batch so
+gradients are SUM-reduced.  The collective is RCCL (torch.distributed backend "nccl") over xGMI, issued per
+bucket while the backward pass is still running.
+"""
+import torch
+import torch.distributed as dist
+
+from .engine import ALIGN
+
+
+class GradBucketer:
+    """Cuts a flat gradient buffer, laid out in backward-completion order, into contiguous buckets and all-reduces
+    (SUM) each bucket as soon as the backward pass has produced it.  Device agnostic: the same object drives RCCL
+    on GPUs and gloo in the CPU tests."""
+
+    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None):
+        """boundaries: increasing element offsets at which a gradient range [0, off) can become final."""
+        self.flat = flat_grad
+        self.group = group
+        self.bounds = []
+        last, limit = 0, max(bucket_bytes // 4, 1)
+        for off in boundaries:
+            if off - last >= limit:
+                self.bounds.append(off)
+                last = off
+        n = flat_grad.numel()
+        if not self.bounds or self.bounds[-1] != n:
+            self.bounds.append(n)
+        self.reset()
+
+    def reset(self):
+        self.next = 0
+        self.sent = 0
+        self.works = []
+
+    def buckets(self):
+        lo = 0
+        for hi in self.bounds:
+            yield lo, hi
+            lo = hi
+
+    def mark_ready(self, offset_end):
+        """Everything in [0, offset_end) is final (the launches that write it are enqueued)."""
+        while self.next < len(self.bounds) and self.bounds[self.next] <= offset_end:
+            hi = self.bounds[self.next]
+            self.works.append(dist.all_reduce(self.flat[self.sent:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                              async_op=True))
+            self.sent = hi
+            self.next += 1
+
+    def finish(self):
+        self.mark_ready(self.flat.numel())
+        for w in self.works:
+            w.wait()
+        self.works = []
+        self.next = 0
+        self.sent = 0
+
+
+def lr_schedule(lr0, epoch, decay=(True, 80)):
+    """main_training.py:342-344: from epoch >= 80 the rate is lr0 * 0.9 ** (epoch / 80)."""
+    if decay and decay[0] and epoch >= decay[1]:
+        return lr0 * 0.9 ** (epoch / decay[1])
+    return lr0
+
+
+class Trainer:
+    """Drives a UNetEngine: one call of ``step`` = one ``distributed_train_step`` of main_training.py:323-327."""
+
+    def __init__(self, engine, lr=5e-7, alpha=0.9, world_size=1, group=None, bucket_bytes=32 << 20, dropout=True):
+        self.engine = engine
+        self.lr, self.alpha = lr, alpha
+        self.world_size = world_size
+        self.group = group
+        self.dropout = dropout
+        self.bucketer = None
+        engine.n_replicas = world_size
+        if world_size > 1:
+            bounds = [s_.offset + (-(-s_.numel // ALIGN) * ALIGN) for s_ in engine.specs.values()]
+            self.bucketer = GradBucketer(engine.grad, bounds, bucket_bytes, group)
+
+    def broadcast_parameters(self, src=0):
+        """Replicas start from identical variables (MirroredStrategy mirrors them at creation)."""
+        if self.world_size > 1:
+            dist.broadcast(self.engine.theta, src=src, group=self.group)
+            for b in self.engine.moving.values():
+                dist.broadcast(b, src=src, group=self.group)
+            self.engine.t_dirty = True
+
+    def step(self, spec_in, emb, spec_out, dropout_mask=None, lr=None, return_loss=False):
+        """inputs as DataGenerator.__getitem__ yields them (datageneratorv2.py:101-102), NCHW, per-replica shard."""
+        eng = self.engine
+        eng.training = True
+        if dropout_mask is None and self.dropout:
+            dropout_mask = eng.make_dropout_mask()
+        gb = eng.B * self.world_size
+        eng.forward(spec_in, emb, dropout_mask=dropout_mask, target=spec_out, global_batch=gb, alpha=self.alpha)
+        if self.bucketer is not None:
+            self.bucketer.reset()
+            eng.backward(on_ready=self.bucketer.mark_ready)
+            self.bucketer.finish()
+        else:
+            eng.backward()
+        if return_loss:
+            eng.reg_loss()                      # on the pre-update weights, as compute_loss sees them
+        eng.adam_step(self.lr if lr is None else lr)
+        if return_loss:
+            return self.last_loss()
+        return None
+
+    def last_loss(self):
+        """Scalar loss of the last step incl. the l2 term (host sync).  Per-replica share: SUM over replicas gives the
+        value strategy.reduce(SUM, ...) returns (main_training.py:326)."""
+        eng = self.engine
+        return float(eng.loss_out[0]) + float(eng.reg_out[0])
