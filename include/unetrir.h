@@ -139,6 +139,18 @@ int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, 
 int unetrir_sigmoid_bwd_f32(const float* pred, const float* dpred, int B, int H, int W,
                             float* dlogits, unetrir_stream_t stream);
 
+/* ---- output head Conv2D(2, (6,6), padding='same') (dl_models/u_net.py:248), direct (non-MFMA) kernels: with 2
+ *      output channels an implicit GEMM would waste 15/16 of every MFMA tile.  C % 16 == 0.
+ *      fwd: w is [>=2][6][6][C] (rows 0,1 used); y is [B*H*W][ldy], ldy >= 2; with ldy >= 4 channels 2,3 are zeroed.
+ *      wgrad: dw[0..1][6][6][C] = sum_pixels dy[p][0..1] * x[p+off][c]; dy is [B*H*W][lddy>=2]; further rows of a
+ *      padded kernel gradient are left untouched.  ws >= unetrir_head6x6_wgrad_ws_bytes(C). */
+int unetrir_head6x6_supported(int C);
+int unetrir_head6x6_fwd_f32(const float* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias,
+                            float* y, int ldy, unetrir_stream_t stream);
+size_t unetrir_head6x6_wgrad_ws_bytes(int C);
+int unetrir_head6x6_wgrad_f32(const float* x, int ldx, int B, int H, int W, int C, const float* dy, int lddy,
+                              float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+
 /* ---- information vector branch: Embedding(2000,256) -> Flatten (dl_models/u_net.py:257-258).
  *      idx int32 [n_idx]; out [n_idx][dim].  Backward is a deterministic gather-by-row:
  *      dtable[v] = sum over positions with idx == v, in position order. */

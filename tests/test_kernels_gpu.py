@@ -265,3 +265,31 @@ def test_embedding_adam_misc(U):
     assert abs(float(acc) - (1.5 + 0.001 * float((g.double() ** 2).sum()))) < 1e-5
     assert torch.equal(y.cpu(), x * k)
     assert torch.equal(pa.base[..., :2].cpu(), nchw.permute(0, 2, 3, 1)) and float(pa.base[..., 2:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 20, 37, 16), (1, 32, 32, 64), (3, 16, 16, 32)])
+def test_head6x6_direct(U, B, H, W, Cc):
+    """The direct (non-MFMA) head kernels against the oracle: Conv2D(2,(6,6),'same') forward and weight gradient."""
+    ops = U.ops
+    x = torch.tensor(detrand.uniform(f"hx{B,H,W,Cc}", (B, Cc, H, W), -1, 1, np.float64))
+    w = torch.tensor(detrand.uniform(f"hw{Cc}", (6, 6, Cc, 2), -1, 1, np.float64), requires_grad=True)
+    b = torch.tensor(detrand.uniform("hb", (2,), -1, 1, np.float64))
+    y = R.conv2d_same(x, w, b, 1)
+    gy = torch.tensor(detrand.uniform(f"hg{B,H,W}", (B, 2, H, W), -1, 1, np.float64))
+    (y * gy).sum().backward()
+    xa = ops.Act(to_nhwc_buf(x, Cc + 4, 4, DEV), 4, Cc)
+    w4 = torch.zeros((4, 6, 6, Cc), device=DEV); w4[:2] = w.detach().permute(3, 0, 1, 2).float().to(DEV)
+    b4 = torch.zeros(4, device=DEV); b4[:2] = b.float().to(DEV)
+    ya = ops.Act(torch.full((B, H, W, 4), 5.0, device=DEV))
+    ops.head6x6_fwd(xa, w4, b4, ya)
+    torch.cuda.synchronize()
+    close(ya.dense()[..., :2].permute(0, 3, 1, 2), y.detach(), 2e-6 * math.sqrt(36 * Cc) + 1e-6, "head fwd")
+    assert float(ya.dense()[..., 2:].abs().max()) == 0.0
+    gya = ops.Act(to_nhwc_buf(gy, 4, 0, DEV), 0, 4)
+    gya.base[..., 2:] = 0
+    dw = torch.zeros((4, 6, 6, Cc), device=DEV)
+    ws = ops.Workspace(DEV)
+    ops.head6x6_wgrad(xa, gya, dw, ws)
+    torch.cuda.synchronize()
+    close(dw[:2], w.grad.permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "head wgrad")
+    assert float(dw[2:].abs().max()) == 0.0

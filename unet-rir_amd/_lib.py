@@ -50,6 +50,12 @@ _SIGS = {
                                        c_stream]),
     "unetrir_nchw_to_nhwc_pad_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                                c_stream]),
+    "unetrir_head6x6_supported": (C.c_int, [C.c_int]),
+    "unetrir_head6x6_fwd_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
+                                          C.c_int, c_stream]),
+    "unetrir_head6x6_wgrad_ws_bytes": (C.c_size_t, [C.c_int]),
+    "unetrir_head6x6_wgrad_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p,
+                                            C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_loss_ws_bytes": (C.c_size_t, [C.c_longlong]),
     "unetrir_sigmoid_loss_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                            c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),

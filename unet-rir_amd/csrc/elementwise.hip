@@ -108,15 +108,27 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
     }
 }
 
+// Block-wide (64 threads, one block per channel) fixed-order sum of the per-slab partials of channel c.
+__device__ __forceinline__ void slab_sum(const double* __restrict__ part, int nslab, int C, int c, double& s, double& ss) {
+    __shared__ double red[64 * 2];
+    double a = 0, b = 0;
+    for (int k = threadIdx.x; k < nslab; k += 64) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+    red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
+    __syncthreads();
+    s = 0; ss = 0;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 64; ++k) { s += red[k * 2]; ss += red[k * 2 + 1]; }
+}
+
 // stage 2 (BN statistics): mean / biased variance -> affine, saved, moving statistics
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                    float* __restrict__ affine, float* __restrict__ saved) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int k = 0; k < nslab; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+    const int c = blockIdx.x;
+    double s, ss;
+    slab_sum(part, nslab, C, c, s, ss);
+    if (threadIdx.x != 0) return;
     const double mean = s / (double)P;
     double var = ss / (double)P - mean * mean;
     if (var < 0) var = 0;
@@ -136,21 +148,20 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nslab, l
 
 // stage 2 (column sum): out[c] = sum_slabs
 __global__ void colsum_finalize_kernel(const double* __restrict__ part, int nslab, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int k = 0; k < nslab; ++k) s += part[((size_t)k * C + c) * 2];
-    out[c] = (float)s;
+    const int c = blockIdx.x;
+    double s, ss;
+    slab_sum(part, nslab, C, c, s, ss);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // stage 2 (BN backward): dgamma, dbeta and the two means the dx pass needs -> coef[2*C]
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int k = 0; k < nslab; ++k) { s += part[((size_t)k * C + c) * 2]; ss += part[((size_t)k * C + c) * 2 + 1]; }
+    const int c = blockIdx.x;
+    double s, ss;
+    slab_sum(part, nslab, C, c, s, ss);
+    if (threadIdx.x != 0) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)ss;
     coef[c] = (float)(s / (double)P);
@@ -272,9 +283,9 @@ __global__ __launch_bounds__(256) void sigmoid_loss_kernel(const float* __restri
 
 __global__ void loss_finalize_kernel(const double* __restrict__ part, int nblk, float alpha, float inv_norm,
                                      float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double sa = 0, sp = 0;
-    for (int k = 0; k < nblk; ++k) { sa += part[k * 2]; sp += part[k * 2 + 1]; }
+    double sa, sp;
+    slab_sum(part, nblk, 1, 0, sa, sp);
+    if (threadIdx.x != 0) return;
     out[0] = (float)(((double)alpha * sa + (1.0 - (double)alpha) * sp) * (double)inv_norm);
     out[1] = (float)sa;
     out[2] = (float)sp;
@@ -414,7 +425,7 @@ int unetrir_bn_stats_f32(const float* x, int ldx, long long P, int C, const floa
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
                        beta, eps, momentum, moving_mean, moving_var, affine, saved);
     return (int)hipGetLastError();
 }
@@ -440,7 +451,7 @@ int unetrir_bn_bwd_f32(const float* da, int ldda, const float* x, int ldx, long 
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
     hipLaunchKernelGGL(chan_partial_kernel<2>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)part, pl.nslab, P, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part, pl.nslab, P, C,
                        dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, relu, dx, lddx);
@@ -454,7 +465,7 @@ int unetrir_colsum_f32(const float* x, int ldx, long long P, int C, float* out, 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(chan_partial_kernel<1>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const float*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, C, out);
     return (int)hipGetLastError();
 }
 

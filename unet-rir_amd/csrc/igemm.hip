@@ -403,12 +403,15 @@ int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* 
     int err = (int)hipGetLastError();
     if (err) return err;
     if (!direct) {
-        const size_t nthreads = (nout + 3) / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s,
-                           (const float*)ws, nsplit, nout, dw, reg, w);
-        err = (int)hipGetLastError();
+        err = launch_splitk_reduce((const float*)ws, nsplit, nout, dw, reg, w, s);
     }
     return err;
+}
+
+int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s) {
+    const size_t nthreads = (n + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, part, nsplit, n, out, reg, w);
+    return (int)hipGetLastError();
 }
 
 int launch_transpose_weight(const float* w, float* wt, int N, int T, int C, hipStream_t s) {

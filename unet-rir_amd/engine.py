@@ -77,6 +77,9 @@ class UNetEngine:
         self._reserve_workspace()
         self.training = True
         self.t_dirty = True
+        self.head_direct = ops.head6x6_supported(self.ch[0])
+        if self.head_direct:
+            self.ws.reserve(512 * 2 * 36 * self.ch[0] * 4)
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self):
@@ -389,7 +392,10 @@ class UNetEngine:
             ops.conv2d_fwd(self.geo[f"dec{l}.cb1b"], self.aa[l], p[f"dec{l}.cb1b.kernel"], p[f"dec{l}.cb1b.bias"], self.yb[l])
             self._bn_relu_fwd(f"dec{l}.cb1b", self.yb[l], self.ab[l])
             cur = self.ab[l]
-        ops.conv2d_fwd(self.geo["head"], cur, p["head.kernel"], p["head.bias"], self.logits)
+        if self.head_direct:
+            ops.head6x6_fwd(cur, p["head.kernel"], p["head.bias"], self.logits)
+        else:
+            ops.conv2d_fwd(self.geo["head"], cur, p["head.kernel"], p["head.bias"], self.logits)
         if target is not None:
             gb = B if global_batch is None else global_batch
             inv_norm = 1.0 / (2.0 * self.H * self.W * gb)
@@ -424,7 +430,10 @@ class UNetEngine:
                 on_ready(s_.offset + (-(-s_.numel // ALIGN) * ALIGN))
 
         gl = self.g_logits
-        ops.conv2d_wgrad(self.geo["head"], self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws)
+        if self.head_direct:
+            ops.head6x6_wgrad(self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws)   # rows 2,3 of the padded kernel stay 0
+        else:
+            ops.conv2d_wgrad(self.geo["head"], self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws)
         ops.colsum(gl, g["head.bias"], ws)
         ready("head.bias")
         top = self.ab[1] if D >= 1 else self.a[1]

@@ -181,6 +181,22 @@ def nchw_to_nhwc_pad(x, y: Act):
     check(_lib.lib().unetrir_nchw_to_nhwc_pad_f32(_p(x), B, C_, H, W, _p(y), y.ld, _stream()), "nchw_to_nhwc_pad")
 
 
+def head6x6_supported(C_):
+    return bool(_lib.lib().unetrir_head6x6_supported(C_))
+
+
+def head6x6_fwd(x: Act, w, bias, y: Act):
+    """Conv2D(2, (6,6), padding='same') (dl_models/u_net.py:248), direct kernel."""
+    check(_lib.lib().unetrir_head6x6_fwd_f32(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(w), _p(bias), _p(y), y.ld, _stream()),
+          "head6x6_fwd")
+
+
+def head6x6_wgrad(x: Act, dy: Act, dw, ws: Workspace):
+    ws.reserve(_lib.lib().unetrir_head6x6_wgrad_ws_bytes(x.C))
+    check(_lib.lib().unetrir_head6x6_wgrad_f32(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(dy), dy.ld, _p(dw), ws.ptr, ws.nbytes,
+                                               _stream()), "head6x6_wgrad")
+
+
 def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_out, ws: Workspace):
     """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits."""
     B, _, H, W = target.shape
