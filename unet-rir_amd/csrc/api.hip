@@ -127,6 +127,10 @@ void wgrad_args(const unetrir_conv_geom* g, int ldx, int lddy, WgradArgs* a) {
 }
 
 size_t wgrad_ws_bytes(const unetrir_conv_geom* g) {
+    if (g->k == 3) {
+        const Same sy = same_geom(g->H, 3, g->stride), sx = same_geom(g->W, 3, g->stride);
+        return wgrad3x3_ws_bytes(g->stride, g->B, sy.out, sx.out, g->Cout, g->Cin);
+    }
     WgradArgs a{};
     wgrad_args(g, g->Cin, g->Cout, &a);
     int ns; long long per;
@@ -136,6 +140,15 @@ size_t wgrad_ws_bytes(const unetrir_conv_geom* g) {
 
 int conv_wgrad_impl(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy, int lddy, float* dw,
                     float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (g->k == 3) {   // 3x3: halo-staged patch kernel (wgrad3x3.hip)
+        const Same sy = same_geom(g->H, 3, g->stride), sx = same_geom(g->W, 3, g->stride);
+        Wgrad3Args a3{};
+        a3.x = x; a3.ldx = ldx; a3.IH = g->H; a3.IW = g->W;
+        a3.dy = dy; a3.lddy = lddy; a3.OH = sy.out; a3.OW = sx.out;
+        a3.B = g->B; a3.C = g->Cin; a3.N = g->Cout;
+        a3.pad_t = sy.before; a3.pad_l = sx.before;
+        return launch_wgrad3x3(a3, g->stride, dw, reg, w, ws, ws_bytes, s);
+    }
     WgradArgs a{};
     wgrad_args(g, ldx, lddy, &a);
     a.x = x; a.dy = dy;

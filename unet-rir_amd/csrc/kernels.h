@@ -43,3 +43,15 @@ int wgrad_plan(const IgemmGeom& g, int* nsplit, long long* chunks_per_split);
 int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_transpose_weight(const float* w, float* wt, int N, int T, int C, hipStream_t s);
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s);
+
+// 3x3 weight gradient with a halo-staged x patch (wgrad3x3.hip)
+struct Wgrad3Args {
+    const float* x; int ldx; int IH, IW;      // layer input  [B,IH,IW,C]
+    const float* dy; int lddy; int OH, OW;    // output grad  [B,OH,OW,N]
+    int B, C, N;
+    int pad_t, pad_l;                         // TF 'same' pad_before per axis
+    float* part;                              // [nsplit][N][9][C]
+    int patches_per_split, npy, npx;
+};
+size_t wgrad3x3_ws_bytes(int stride, int B, int OH, int OW, int N, int C);
+int launch_wgrad3x3(Wgrad3Args a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);

@@ -8,6 +8,8 @@ holds the full model, BatchNorm statistics stay per replica, the loss is normali
 gradients are SUM-reduced.  The collective is RCCL (torch.distributed backend "nccl") over xGMI, issued per
 bucket while the backward pass is still running.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -81,7 +83,8 @@ class Trainer:
         self.dropout = dropout
         self.bucketer = None
         engine.n_replicas = world_size
-        if world_size > 1:
+        # UNETRIR_FORCE_DP=1 exercises the bucketed all-reduce path on a 1-rank process group (single-GPU rehearsal)
+        if world_size > 1 or (os.environ.get("UNETRIR_FORCE_DP") == "1" and dist.is_initialized()):
             bounds = [s_.offset + (-(-s_.numel // ALIGN) * ALIGN) for s_ in engine.specs.values()]
             self.bucketer = GradBucketer(engine.grad, bounds, bucket_bytes, group)
 
