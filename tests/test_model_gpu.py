@@ -156,3 +156,10 @@ def test_module_dropin_autograd(U):
     assert out_eval.shape == (B, H, W, 2) and bool(torch.isfinite(out_eval).all())
     with pytest.raises(NotImplementedError):
         U.UNet((H, W, 2), (2, 16), mode=1, batch_size=B, device=DEV)
+
+
+def test_depth5_graph(U):
+    """BASELINE configs[3] shape class: 5 down / 5 up (constructor extension `depth`), reduced size."""
+    cfg, Pn, eng, tr, ref, _ = run_case(U, 64, 64, 4, 2, depth=5)
+    assert eng.hw[-1] == (2, 2) and eng.ch[-1] == 4 * 32
+    check_against_oracle(eng, ref)

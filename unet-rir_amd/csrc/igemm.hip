@@ -30,7 +30,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ------------------------------------------------------------------------------------------------
 // forward-type kernel:  out[opix(p)][n] = bias[n] + addend + sum_t sum_c in[ipix(p,t)][c] * w[n][widx_t][c]
 // ------------------------------------------------------------------------------------------------
-template <int BN_>
+template <int BN_, bool UNIFORM>
 __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     constexpr int NSUB = BN_ / 64;        // 32-wide N sub-tiles per wave (waves are 2 x 2)
     constexpr int NB = BN_ / 32;          // B-tile rows loaded per thread
@@ -60,44 +60,68 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
 
     // loader mapping: 8 threads cover the 32 k-values of one row; 32 rows per pass
     const int quad = tid & 7, lrow = tid >> 3;
-    int kt = (quad * 4) / C, kc = (quad * 4) % C;          // (tap, channel) of this thread's k-quad
+    // (tap, channel) of the k-quad being staged.  UNIFORM (C % 32 == 0): a stage never straddles a tap, so the
+    // tap index and the channel base are wave-uniform scalars and only quad*4 is per lane.
+    int kt = UNIFORM ? 0 : (quad * 4) / C;
+    int kc = UNIFORM ? 0 : (quad * 4) % C;
 
-    int a_by[4], a_bx[4], a_img[4];
+    __syncthreads();   // s_tap visible
+
+    // per staged row: pointer to its centre pixel (tap offset 0) and a bit mask of the taps that fall inside the image
+    const float* a_ptr[4];
+    unsigned long long a_mask[4];
     const int plane = a.g.PH * a.g.PW;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long long p = m0 + lrow + 32 * j;
+        a_ptr[j] = a.in;
+        a_mask[j] = 0ull;
         if (p < M) {
             const int n = (int)(p / plane);
             const int rem = (int)(p - (long long)n * plane);
             const int py = rem / a.g.PW, px = rem - py * a.g.PW;
-            a_by[j] = py * a.g.SI; a_bx[j] = px * a.g.SI; a_img[j] = n * IH;
-        } else {
-            a_by[j] = -(1 << 28); a_bx[j] = 0; a_img[j] = 0;   // always out of range -> zero fill
+            const int by = py * a.g.SI, bx = px * a.g.SI;
+            a_ptr[j] = a.in + ((long long)((long long)n * IH + by) * IW + bx) * ldi;
+            unsigned long long m = 0ull;
+            for (int t = 0; t < ntaps; ++t) {
+                const uint32_t e = s_tap[t];
+                const int iy = by + (int)(int8_t)(e & 0xff), ix = bx + (int)(int8_t)((e >> 8) & 0xff);
+                if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) m |= 1ull << t;
+            }
+            a_mask[j] = m;
         }
+    }
+    const float* b_ptr[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + lrow + 32 * j;
+        b_ok[j] = n < a.g.N;
+        b_ptr[j] = a.w + (size_t)(b_ok[j] ? n : 0) * ldw;
     }
 
     float4 ra[4], rb[NB];
-    __syncthreads();   // s_tap visible
 
     auto load_stage = [&]() {
-        const bool kok = kt < ntaps;
-        const uint32_t e = kok ? s_tap[kt] : 0u;
+        int t = kt, c = kc;
+        if (UNIFORM) { t = __builtin_amdgcn_readfirstlane(t); c = __builtin_amdgcn_readfirstlane(c); }
+        const bool kok = t < ntaps;
+        uint32_t e = kok ? s_tap[t] : 0u;
+        if (UNIFORM) e = __builtin_amdgcn_readfirstlane(e);
         const int dy = (int)(int8_t)(e & 0xff), dx = (int)(int8_t)((e >> 8) & 0xff);
         const int wi = (int)((e >> 16) & 0xff);
+        const int aoff = (dy * IW + dx) * ldi + c + (UNIFORM ? quad * 4 : 0);
+        const int boff = wi * C + c + (UNIFORM ? quad * 4 : 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int iy = a_by[j] + dy, ix = a_bx[j] + dx;
-            const bool ok = kok && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float4*>(a.in + ((size_t)(a_img[j] + iy) * IW + ix) * ldi + kc);
+            if (kok && ((a_mask[j] >> t) & 1ull)) v = *reinterpret_cast<const float4*>(a_ptr[j] + aoff);
             ra[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int n = n0 + lrow + 32 * j;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kok && n < a.g.N) v = *reinterpret_cast<const float4*>(a.w + (size_t)n * ldw + wi * C + kc);
+            if (kok && b_ok[j]) v = *reinterpret_cast<const float4*>(b_ptr[j] + boff);
             rb[j] = v;
         }
     };
@@ -133,15 +157,23 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
             for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4*>(&As[(arow + 32 * i) * LDS_LD + kk * 8 + koff]);
 #pragma unroll
             for (int j = 0; j < NSUB; ++j) fb[j] = *reinterpret_cast<const float4*>(&Bs[(brow + 32 * j) * LDS_LD + kk * 8 + koff]);
+            // k-major order: consecutive MFMAs hit different accumulators (dependent latency == issue interval)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
     }
 
@@ -361,11 +393,14 @@ int launch_igemm_fwd(const IgemmArgs& a, hipStream_t s) {
     const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
     if (M <= 0 || a.g.N <= 0) return 0;
     const long long mt = (M + BM - 1) / BM;
+    const bool uniform = (a.g.C % BK) == 0;
     if (a.g.N > 64) {
         const long long nwg = mt * ((a.g.N + 127) / 128);
-        hipLaunchKernelGGL(igemm_fwd_kernel<128>, dim3((unsigned)nwg), dim3(256), 0, s, a);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_kernel<128, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<128, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL(igemm_fwd_kernel<64>, dim3((unsigned)mt), dim3(256), 0, s, a);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_kernel<64, true>), dim3((unsigned)mt), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<64, false>), dim3((unsigned)mt), dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();
 }
