@@ -34,6 +34,7 @@ extern "C" {
 #define UNETRIR_ABI_VERSION 1
 
 typedef void* unetrir_stream_t; /* hipStream_t */
+typedef uint16_t unetrir_bf16;  /* bfloat16 storage (upper 16 bits of an IEEE fp32) */
 
 /* Geometry of one Conv2D / Conv2DTranspose(padding='same') call.
  * H, W: spatial size of the layer INPUT (for the transpose: the low-res input). */
@@ -170,6 +171,65 @@ int unetrir_sumsq_f32(const float* x, long long n, float coef, float* out, int a
 int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long n, float lr_t,
                      float beta1, float beta2, float eps, float grad_scale,
                      unetrir_stream_t stream);
+
+/* ---- bf16-storage variants (BASELINE.json configs[1] names bf16): activations, their gradients and the weight work
+ *      copies are bfloat16 (unetrir_bf16), accumulation is fp32 (v_mfma_f32_32x32x16_bf16), bias / BatchNorm parameters /
+ *      statistics / weight gradients / master weights stay fp32.  Channel counts and pixel strides are multiples of 8
+ *      (16-byte rows).  Same call sites as the _f32 entry points above.  The weight gradient exists for 3x3 kernels
+ *      (the 1x1 conv and the Dense layer of the information-vector branch stay fp32). */
+int unetrir_conv2d_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
+                            const float* bias, const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy,
+                            unetrir_stream_t stream);
+int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
+                              const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx,
+                              unetrir_stream_t stream);
+int unetrir_conv2d_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy,
+                              int lddy, float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
+                              unetrir_stream_t stream);
+int unetrir_conv2d_transpose_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx,
+                                      const unetrir_bf16* wt, const float* bias, unetrir_bf16* y, int ldy,
+                                      unetrir_stream_t stream);
+int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy,
+                                        const unetrir_bf16* w, const unetrir_bf16* addend, int ldadd,
+                                        unetrir_bf16* dx, int lddx, unetrir_stream_t stream);
+int unetrir_conv2d_transpose_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx,
+                                        const unetrir_bf16* dy, int lddy, float* dw, float reg_coef, const float* w,
+                                        void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* fp32 master weights [N][T][C] -> bf16 work copies: same orientation with channels zero-padded to Cp; transposed
+ * [C][T][Np] with the row dimension zero-padded to Np. */
+int unetrir_cast_weight_bf16(const float* w, unetrir_bf16* o, int N, int T, int C, int Cp, unetrir_stream_t stream);
+int unetrir_transpose_cast_weight_bf16(const float* w, unetrir_bf16* wt, int N, int T, int C, int Np,
+                                       unetrir_stream_t stream);
+int unetrir_bn_stats_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* gamma, const float* beta,
+                          float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
+                          float* saved, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+int unetrir_bn_apply_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* affine, int relu,
+                          unetrir_bf16* y, int ldy, unetrir_stream_t stream);
+int unetrir_bn_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x, int ldx, long long P, int C,
+                        const float* affine, const float* saved, int relu, unetrir_bf16* dx, int lddx, float* dgamma,
+                        float* dbeta, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+int unetrir_colsum_bf16(const unetrir_bf16* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes,
+                        unetrir_stream_t stream);
+int unetrir_relu_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x, int ldx, long long P, int C,
+                          unetrir_bf16* dx, int lddx, unetrir_stream_t stream);
+int unetrir_nchw_to_nhwc_pad_bf16(const float* x, int B, int C, int H, int W, unetrir_bf16* y, int Cpad,
+                                  unetrir_stream_t stream);
+/* head: bf16 activations in, fp32 logits [P][ldy] out; weight gradient from bf16 dlogits [P][lddy] */
+int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* w,
+                             const float* bias, float* y, int ldy, unetrir_stream_t stream);
+int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy,
+                               int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* as unetrir_sigmoid_loss_f32 / unetrir_sigmoid_bwd_f32 but dlogits is bf16 [B*H*W][8] (channels 2..7 zero) */
+int unetrir_sigmoid_loss_bf16(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha,
+                              float inv_norm, float* pred, unetrir_bf16* dlogits, float* loss_out, void* ws,
+                              size_t ws_bytes, unetrir_stream_t stream);
+int unetrir_sigmoid_bwd_bf16(const float* pred, const float* dpred, int B, int H, int W, unetrir_bf16* dlogits,
+                             unetrir_stream_t stream);
+/* glue between the bf16 trunk and the fp32 information-vector branch: y = a + b (Add(), dl_models/u_net.py:229);
+ * fp32 copy of a bf16 gradient.  n is a multiple of 4. */
+int unetrir_add_f32_to_bf16(const unetrir_bf16* a, const float* b, unetrir_bf16* y, long long n,
+                            unetrir_stream_t stream);
+int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetrir_stream_t stream);
 
 /* ---- profiling hooks used by bench.py: when enabled every conv launch is bracketed by HIP
  *      events on its own stream; collect() synchronises those events and returns, per kernel

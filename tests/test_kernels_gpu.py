@@ -293,3 +293,170 @@ def test_head6x6_direct(U, B, H, W, Cc):
     torch.cuda.synchronize()
     close(dw[:2], w.grad.permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "head wgrad")
     assert float(dw[2:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16-storage kernels: inputs are rounded to bf16 first, the oracle then runs in fp64 on the SAME rounded values, so the
+# only differences are fp32 accumulation order and the final rounding of bf16 outputs (2^-8 relative).
+# ------------------------------------------------------------------------------------------------------------------
+def q16(t):
+    return t.to(torch.bfloat16).double()
+
+
+def to_nhwc_bf16(x_nchw, ld, c0, dev):
+    B, C, H, W = x_nchw.shape
+    buf = torch.full((B, H, W, ld), 768.0, dtype=torch.bfloat16)
+    buf[..., c0:c0 + C] = x_nchw.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return buf.to(dev)
+
+
+BF16_CONV_CASES = [
+    (2, 16, 24, 8, 16, 3, 1), (2, 16, 24, 16, 32, 3, 2), (1, 9, 7, 8, 8, 3, 2), (2, 8, 8, 64, 128, 3, 1),
+    (1, 10, 12, 40, 72, 3, 1), (1, 12, 12, 64, 8, 6, 1), (2, 16, 16, 128, 64, 3, 1), (1, 32, 32, 8, 64, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CONV_CASES)
+def test_conv2d_bf16(U, case):
+    ops = U.ops
+    B, H, W, Ci, Co, k, s = case
+    x, w, b = conv_data(case)
+    x, w = q16(x), q16(w)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y = R.conv2d_same(x, w, b, s)
+    Ho, Wo = y.shape[2], y.shape[3]
+    add = q16(torch.tensor(detrand.uniform(f"a{case}", (B, Co, Ho, Wo), -1, 1, np.float64)))
+    gy = q16(torch.tensor(detrand.uniform(f"g{case}", (B, Co, Ho, Wo), -1, 1, np.float64)))
+    (y * gy).sum().backward()
+
+    g = ops.geom(B, H, W, Ci, Co, k, s)
+    xa = ops.Act(to_nhwc_bf16(x.detach(), Ci + 8, 8, DEV), 8, Ci)
+    w32 = w.detach().permute(3, 0, 1, 2).contiguous().float().to(DEV)            # [Co][k][k][Ci] fp32 master
+    wh = torch.empty((Co, k * k, Ci), dtype=torch.bfloat16, device=DEV)
+    ops.cast_weight_bf16(w32, wh, Co, k * k, Ci, Ci)
+    ya = ops.Act(torch.full((B, Ho, Wo, Co + 8), 512.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+    adda = ops.Act(to_nhwc_bf16(add, Co, 0, DEV))
+    ops.conv2d_fwd(g, xa, wh, b.float().to(DEV), ya, adda)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y.detach() + add, 1e-2, "bf16 fwd")
+    assert float(ya.base[..., Co:].float().min()) == 512.0
+
+    Np = -(-Co // 8) * 8
+    wt = torch.zeros((Ci, k * k, Np), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_cast_weight_bf16(w32, wt, Co, k * k, Ci, Np)
+    gya = ops.Act(to_nhwc_bf16(gy, Np, 0, DEV), 0, Np)
+    if Np != Co:
+        gya.base[..., Co:] = 0
+    gd = ops.geom(B, H, W, Ci, Np, k, s)
+    dxa = ops.Act(torch.full((B, H, W, Ci), 256.0, dtype=torch.bfloat16, device=DEV))
+    ops.conv2d_dgrad(gd, gya, wt, dxa)
+    torch.cuda.synchronize()
+    close(dxa.dense().permute(0, 3, 1, 2), x.grad, 1e-2, "bf16 dgrad")
+
+    if k == 3:
+        ws = ops.Workspace(DEV)
+        dw = torch.full((Co, k, k, Ci), 111.0, device=DEV)
+        ops.conv2d_wgrad(g, xa, ops.Act(to_nhwc_bf16(gy, Co, 0, DEV)), dw, ws, reg=0.002, w=w32)
+        torch.cuda.synchronize()
+        close(dw, (w.grad + 0.002 * w.detach()).permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * Ho * Wo) + 1e-6, "bf16 wgrad")
+
+
+@pytest.mark.parametrize("case", [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (2, 3, 3, 128, 64, 3)])
+def test_conv2d_transpose_bf16(U, case):
+    ops = U.ops
+    B, H, W, Ci, Co, k = case
+    x = q16(torch.tensor(detrand.uniform(f"tx{case}", (B, Ci, H, W), -1, 1, np.float64))).requires_grad_(True)
+    w = q16(torch.tensor(detrand.uniform(f"tw{case}", (k, k, Co, Ci), -1, 1, np.float64))).requires_grad_(True)
+    b = torch.tensor(detrand.uniform(f"tb{case}", (Co,), -1, 1, np.float64))
+    y = R.conv2d_transpose_same(x, w, b, 2)
+    gy = q16(torch.tensor(detrand.uniform(f"tg{case}", tuple(y.shape), -1, 1, np.float64)))
+    (y * gy).sum().backward()
+    g = ops.geom(B, H, W, Ci, Co, k, 2)
+    w32 = w.detach().permute(3, 0, 1, 2).contiguous().float().to(DEV)            # primary [Ci][k][k][Co]
+    wprim = torch.empty((Ci, k * k, Co), dtype=torch.bfloat16, device=DEV)
+    ops.cast_weight_bf16(w32, wprim, Ci, k * k, Co, Co)
+    wt = torch.zeros((Co, k * k, Ci), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_cast_weight_bf16(w32, wt, Ci, k * k, Co, Ci)
+    xa = ops.Act(to_nhwc_bf16(x.detach(), Ci, 0, DEV))
+    ya = ops.Act(torch.full((B, 2 * H, 2 * W, 2 * Co), 512.0, dtype=torch.bfloat16, device=DEV), Co, Co)
+    ops.conv2d_transpose_fwd(g, xa, wt, b.float().to(DEV), ya)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y.detach(), 1e-2, "bf16 convT fwd")
+    assert float(ya.base[..., :Co].float().min()) == 512.0
+    gya = ops.Act(to_nhwc_bf16(gy, 2 * Co, Co, DEV), Co, Co)
+    dxa = ops.Act(torch.full((B, H, W, Ci), 256.0, dtype=torch.bfloat16, device=DEV))
+    ops.conv2d_transpose_dgrad(g, gya, wprim, dxa)
+    torch.cuda.synchronize()
+    close(dxa.dense().permute(0, 3, 1, 2), x.grad, 1e-2, "bf16 convT dgrad")
+    ws = ops.Workspace(DEV)
+    dw = torch.full((Ci, k, k, Co), 111.0, device=DEV)
+    ops.conv2d_transpose_wgrad(g, xa, gya, dw, ws, reg=0.002, w=w32)
+    torch.cuda.synchronize()
+    close(dw, (w.grad + 0.002 * w.detach()).permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "bf16 convT wgrad")
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 10, 16), (1, 4, 4, 1024), (2, 33, 31, 8)])
+def test_batchnorm_bf16(U, shape):
+    ops = U.ops
+    B, H, W, Cc = shape
+    x = q16(torch.tensor(detrand.uniform(f"bx{shape}", (B, Cc, H, W), -2, 2, np.float64))).requires_grad_(True)
+    gamma = torch.tensor(detrand.uniform(f"bg{shape}", (Cc,), 0.5, 1.5, np.float64), requires_grad=True)
+    beta = torch.tensor(detrand.uniform(f"bb{shape}", (Cc,), -0.5, 0.5, np.float64), requires_grad=True)
+    y = R.bn_relu(x, gamma, beta, None, "bn", True, relu=True)
+    gy = q16(torch.tensor(detrand.uniform(f"bgy{shape}", (B, Cc, H, W), -1, 1, np.float64)))
+    (y * gy).sum().backward()
+    ws = ops.Workspace(DEV)
+    xa = ops.Act(to_nhwc_bf16(x.detach(), Cc + 8, 8, DEV), 8, Cc)
+    aff = torch.empty(2 * Cc, device=DEV); saved = torch.empty(2 * Cc, device=DEV)
+    g32, b32 = gamma.detach().float().to(DEV), beta.detach().float().to(DEV)
+    ops.bn_stats(xa, g32, b32, aff, saved, ws)
+    ya = ops.Act(torch.empty((B, H, W, Cc), dtype=torch.bfloat16, device=DEV))
+    ops.bn_apply(xa, aff, ya, relu=True)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y.detach(), 1e-2, "bf16 bn fwd")
+    gya = ops.Act(to_nhwc_bf16(gy, Cc, 0, DEV))
+    dxa = ops.Act(torch.empty((B, H, W, Cc), dtype=torch.bfloat16, device=DEV))
+    dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
+    ops.bn_bwd(gya, xa, g32, aff, saved, dxa, dg, db, ws, relu=True)
+    cs = torch.empty(Cc, device=DEV)
+    ops.colsum(gya, cs, ws)
+    torch.cuda.synchronize()
+    close(dxa.dense().permute(0, 3, 1, 2), x.grad, 1e-2, "bf16 bn dx")
+    close(dg, gamma.grad, 1e-4, "bf16 dgamma"); close(db, beta.grad, 1e-4, "bf16 dbeta")
+    close(cs, gy.sum(dim=(0, 2, 3)), 1e-5, "bf16 colsum")
+
+
+def test_head_and_loss_bf16(U):
+    ops = U.ops
+    B, H, W, Cc = 2, 20, 37, 32
+    x = q16(torch.tensor(detrand.uniform("hx16", (B, Cc, H, W), -1, 1, np.float64)))
+    w = torch.tensor(detrand.uniform("hw16", (6, 6, Cc, 2), -1, 1, np.float64), requires_grad=True)
+    b = torch.tensor(detrand.uniform("hb16", (2,), -1, 1, np.float64))
+    target = torch.tensor(detrand.uniform("ht16", (B, 2, H, W), 0, 1, np.float64))
+    logits = R.conv2d_same(x, w, b, 1)
+    logits.retain_grad()
+    loss = R.data_loss(target, torch.sigmoid(logits), 0.9, B)
+    loss.backward()
+    xa = ops.Act(to_nhwc_bf16(x, Cc, 0, DEV))
+    w8 = torch.zeros((8, 6, 6, Cc), device=DEV); w8[:2] = w.detach().permute(3, 0, 1, 2).float().to(DEV)
+    b8 = torch.zeros(8, device=DEV); b8[:2] = b.float().to(DEV)
+    la = ops.Act(torch.full((B, H, W, 4), 5.0, device=DEV))
+    ops.head6x6_fwd(xa, w8, b8, la)
+    pr = torch.empty((B, 2, H, W), device=DEV)
+    dl = ops.Act(torch.full((B, H, W, 8), 9.0, dtype=torch.bfloat16, device=DEV))
+    out = torch.zeros(4, device=DEV)
+    ws = ops.Workspace(DEV)
+    ops.sigmoid_loss(la, target.float().to(DEV), 0.9, 1.0 / (2 * H * W * B), pr, dl, out, ws)
+    torch.cuda.synchronize()
+    close(la.dense()[..., :2].permute(0, 3, 1, 2), logits.detach(), 2e-5, "head fwd (bf16 in)")
+    assert abs(float(out[0]) - float(loss.detach())) <= 1e-5 * float(loss.detach())
+    close(dl.dense()[..., :2].permute(0, 3, 1, 2), logits.grad, 1e-2, "dlogits bf16")
+    assert float(dl.dense()[..., 2:].float().abs().max()) == 0.0
+    # weight gradient from the bf16 dlogits the kernel itself produced
+    gl = dl.dense()[..., :2].double().cpu().permute(0, 3, 1, 2)
+    w2 = w.detach().clone().requires_grad_(True)
+    (R.conv2d_same(x, w2, b, 1) * gl).sum().backward()
+    dw = torch.zeros((8, 6, 6, Cc), device=DEV)
+    ops.head6x6_wgrad(xa, dl, dw, ws)
+    torch.cuda.synchronize()
+    close(dw[:2], w2.grad.permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "head wgrad (bf16 in)")

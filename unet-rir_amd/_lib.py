@@ -68,6 +68,42 @@ _SIGS = {
                                     c_stream]),
     "unetrir_adam_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_longlong, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, c_stream]),
+    # ---- bf16-storage variants (same argument lists; pointers are void*) ----
+    "unetrir_conv2d_fwd_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int,
+                                          c_f32p, C.c_int, c_stream]),
+    "unetrir_conv2d_dgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
+                                            C.c_int, c_stream]),
+    "unetrir_conv2d_wgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_float,
+                                            c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_conv2d_transpose_fwd_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
+                                                    C.c_int, c_stream]),
+    "unetrir_conv2d_transpose_dgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int,
+                                                      c_f32p, C.c_int, c_stream]),
+    "unetrir_conv2d_transpose_wgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
+                                                      C.c_float, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_cast_weight_bf16": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "unetrir_transpose_cast_weight_bf16": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "unetrir_bn_stats_bf16": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,
+                                        c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_bn_apply_bf16": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
+                                        c_stream]),
+    "unetrir_bn_bwd_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p,
+                                      C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_colsum_bf16": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_void_p, C.c_size_t,
+                                      c_stream]),
+    "unetrir_relu_bwd_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int,
+                                        c_stream]),
+    "unetrir_nchw_to_nhwc_pad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
+                                                c_stream]),
+    "unetrir_head6x6_fwd_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
+                                           C.c_int, c_stream]),
+    "unetrir_head6x6_wgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
+                                             c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_sigmoid_loss_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                            c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_sigmoid_bwd_bf16": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "unetrir_add_f32_to_bf16": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_longlong, c_stream]),
+    "unetrir_cast_bf16_to_f32": (C.c_int, [c_f32p, c_f32p, C.c_longlong, c_stream]),
     "unetrir_prof_enable": (C.c_int, [C.c_int]),
     "unetrir_prof_collect": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -57,11 +57,22 @@ inline int conv_family(const unetrir_conv_geom* g, int fam) {
     return (g->Cin < 8 || g->Cout < 8) ? 5 : fam;
 }
 
+// element-type policies: fp32 and bf16-storage variants share the tap-table construction
+struct F32 {
+    using T = float; using Args = IgemmArgs;
+    static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd(a, s); }
+};
+struct BF16 {
+    using T = __bf16; using Args = IgemmArgsH;
+    static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd_bf16(a, s); }
+};
+
 // ---- Conv2D forward: iteration grid = output grid ----
-int conv_fwd_impl(const unetrir_conv_geom* g, const float* x, int ldx, const float* w, const float* bias,
-                  const float* addend, int ldadd, float* y, int ldy, hipStream_t s) {
+template <class P>
+int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, const typename P::T* w, const float* bias,
+                  const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s) {
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
-    IgemmArgs a{};
+    typename P::Args a{};
     a.g.B = g->B; a.g.PH = sy.out; a.g.PW = sx.out;
     a.g.IH = g->H; a.g.IW = g->W; a.g.C = g->Cin; a.g.ldi = ldx;
     a.g.OH = sy.out; a.g.OW = sx.out; a.g.N = g->Cout; a.g.ldo = ldy;
@@ -71,15 +82,16 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const float* x, int ldx, const flo
         for (int kw = 0; kw < g->k; ++kw)
             a.g.tap[kh * g->k + kw] = pack_tap(kh - sy.before, kw - sx.before, kh * g->k + kw);
     a.in = x; a.w = w; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = y;
-    return launch_igemm_fwd(a, s);
+    return P::launch(a, s);
 }
 
 // ---- Conv2D data gradient (also Conv2DTranspose forward when `bias` is given) ----
 // dx[q][ci] = sum_t sum_co dy[p][co] * wt[ci][t][co]  with q = p*s + (k_t - pad_before)
-int conv_dgrad_impl(const unetrir_conv_geom* g, const float* dy, int lddy, const float* wt, const float* bias,
-                    const float* addend, int ldadd, float* dx, int lddx, hipStream_t s) {
+template <class P>
+int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int lddy, const typename P::T* wt, const float* bias,
+                    const typename P::T* addend, int ldadd, typename P::T* dx, int lddx, hipStream_t s) {
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
-    IgemmArgs a{};
+    typename P::Args a{};
     a.g.B = g->B;
     a.g.IH = sy.out; a.g.IW = sx.out; a.g.C = g->Cout; a.g.ldi = lddy;
     a.g.OH = g->H; a.g.OW = g->W; a.g.N = g->Cin; a.g.ldo = lddx;
@@ -91,7 +103,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const float* dy, int lddy, const
         for (int kh = 0; kh < g->k; ++kh)
             for (int kw = 0; kw < g->k; ++kw)
                 a.g.tap[kh * g->k + kw] = pack_tap(-(kh - sy.before), -(kw - sx.before), kh * g->k + kw);
-        return launch_igemm_fwd(a, s);
+        return P::launch(a, s);
     }
     // stride 2: one launch per output parity class (ay, ax); q = 2p' + a, p = p' + (a - off)/2
     a.g.PH = (g->H + 1) / 2; a.g.PW = (g->W + 1) / 2; a.g.SI = 1; a.g.SO = 2;
@@ -108,7 +120,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const float* dy, int lddy, const
                 }
             }
             a.g.ntaps = nt; a.g.ooy = ay; a.g.oox = ax;
-            const int err = launch_igemm_fwd(a, s);
+            const int err = P::launch(a, s);
             if (err) return err;
         }
     return 0;
@@ -155,6 +167,18 @@ int conv_wgrad_impl(const unetrir_conv_geom* g, const float* x, int ldx, const f
     return launch_igemm_wgrad(a, dw, reg, w, ws, ws_bytes, s);
 }
 
+int conv_wgrad_bf16_impl(const unetrir_conv_geom* g, const __bf16* x, int ldx, const __bf16* dy, int lddy, float* dw, float reg,
+                         const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (g->k != 3) return UNETRIR_EINVAL;       // bf16 weight gradients exist for the 3x3 layers (the others stay fp32)
+    const Same sy = same_geom(g->H, 3, g->stride), sx = same_geom(g->W, 3, g->stride);
+    Wgrad3ArgsH a3{};
+    a3.x = x; a3.ldx = ldx; a3.IH = g->H; a3.IW = g->W;
+    a3.dy = dy; a3.lddy = lddy; a3.OH = sy.out; a3.OW = sx.out;
+    a3.B = g->B; a3.C = g->Cin; a3.N = g->Cout;
+    a3.pad_t = sy.before; a3.pad_l = sx.before;
+    return launch_wgrad3x3_bf16(a3, g->stride, dw, reg, w, ws, ws_bytes, s);
+}
+
 // Conv2DTranspose(k, s=2, 'same') on an H x W input is the adjoint of Conv2D(k, s=2, 'same') that maps the
 // 2H x 2W grid back to H x W: swap the channel roles and double the spatial size.
 inline unetrir_conv_geom adjoint_geom(const unetrir_conv_geom* g) {
@@ -165,6 +189,7 @@ inline unetrir_conv_geom adjoint_geom(const unetrir_conv_geom* g) {
 }
 
 inline bool ld_ok(int ld, int c) { return ld >= c && (ld & 3) == 0; }
+inline bool ldh_ok(int ld, int c) { return ld >= c && (ld & 7) == 0; }     // bf16: 16-byte rows
 
 }  // namespace
 
@@ -176,14 +201,14 @@ int unetrir_conv2d_fwd_f32(const unetrir_conv_geom* g, const float* x, int ldx, 
                            const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream) {
     if (!geom_ok(g) || !x || !w || !y || (g->Cin & 3) || !ld_ok(ldx, g->Cin) || ldy < g->Cout) return UNETRIR_EINVAL;
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
-    return conv_fwd_impl(g, x, ldx, w, bias, addend, ldadd, y, ldy, (hipStream_t)stream);
+    return conv_fwd_impl<F32>(g, x, ldx, w, bias, addend, ldadd, y, ldy, (hipStream_t)stream);
 }
 
 int unetrir_conv2d_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy, const float* wt,
                              const float* addend, int ldadd, float* dx, int lddx, unetrir_stream_t stream) {
     if (!geom_ok(g) || !dy || !wt || !dx || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || lddx < g->Cin) return UNETRIR_EINVAL;
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
-    return conv_dgrad_impl(g, dy, lddy, wt, nullptr, addend, ldadd, dx, lddx, (hipStream_t)stream);
+    return conv_dgrad_impl<F32>(g, dy, lddy, wt, nullptr, addend, ldadd, dx, lddx, (hipStream_t)stream);
 }
 
 size_t unetrir_conv2d_wgrad_ws_bytes(const unetrir_conv_geom* g) { return geom_ok(g) ? wgrad_ws_bytes(g) : 0; }
@@ -203,7 +228,7 @@ int unetrir_conv2d_transpose_fwd_f32(const unetrir_conv_geom* g, const float* x,
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
-    return conv_dgrad_impl(&c, x, ldx, wt, bias, nullptr, 0, y, ldy, (hipStream_t)stream);
+    return conv_dgrad_impl<F32>(&c, x, ldx, wt, bias, nullptr, 0, y, ldy, (hipStream_t)stream);
 }
 
 int unetrir_conv2d_transpose_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy, const float* w,
@@ -212,7 +237,7 @@ int unetrir_conv2d_transpose_dgrad_f32(const unetrir_conv_geom* g, const float* 
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(&c), (hipStream_t)stream);
-    return conv_fwd_impl(&c, dy, lddy, w, nullptr, addend, ldadd, dx, lddx, (hipStream_t)stream);
+    return conv_fwd_impl<F32>(&c, dy, lddy, w, nullptr, addend, ldadd, dx, lddx, (hipStream_t)stream);
 }
 
 size_t unetrir_conv2d_transpose_wgrad_ws_bytes(const unetrir_conv_geom* g) {
@@ -231,6 +256,76 @@ int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* 
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_WGRAD), conv_flops(&c), (hipStream_t)stream);
     // adjoint conv: its "x" is our dy (2H x 2W, Cout channels), its "dy" is our x (H x W, Cin channels)
     return conv_wgrad_impl(&c, dy, lddy, x, ldx, dw, reg_coef, w, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* ---- bf16-storage variants: x / dy / y / dx and the weight work copies are bf16, bias fp32, weight gradients fp32 ---- */
+int unetrir_conv2d_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w, const float* bias,
+                            const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !w || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout) return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
+    return conv_fwd_impl<BF16>(g, (const __bf16*)x, ldx, (const __bf16*)w, bias, (const __bf16*)addend, ldadd, (__bf16*)y, ldy,
+                               (hipStream_t)stream);
+}
+
+int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
+                              const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !dy || !wt || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin) return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
+    return conv_dgrad_impl<BF16>(g, (const __bf16*)dy, lddy, (const __bf16*)wt, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx,
+                                 lddx, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy, int lddy,
+                              float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !dy || !dw || (g->Cin & 7) || (g->Cout & 7) || !ldh_ok(ldx, g->Cin) || !ldh_ok(lddy, g->Cout) ||
+        (reg_coef != 0.f && !w))
+        return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_WGRAD), conv_flops(g), (hipStream_t)stream);
+    return conv_wgrad_bf16_impl(g, (const __bf16*)x, ldx, (const __bf16*)dy, lddy, dw, reg_coef, w, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_transpose_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* wt,
+                                      const float* bias, unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
+    if (!geom_ok(g) || g->stride != 2 || !x || !wt || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout)
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
+    return conv_dgrad_impl<BF16>(&c, (const __bf16*)x, ldx, (const __bf16*)wt, bias, nullptr, 0, (__bf16*)y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* w,
+                                        const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx,
+                                        unetrir_stream_t stream) {
+    if (!geom_ok(g) || g->stride != 2 || !dy || !w || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin)
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(&c), (hipStream_t)stream);
+    return conv_fwd_impl<BF16>(&c, (const __bf16*)dy, lddy, (const __bf16*)w, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx, lddx,
+                               (hipStream_t)stream);
+}
+
+int unetrir_conv2d_transpose_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy,
+                                        int lddy, float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
+                                        unetrir_stream_t stream) {
+    if (!geom_ok(g) || g->stride != 2 || !x || !dy || !dw || (g->Cin & 7) || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) ||
+        !ldh_ok(ldx, g->Cin) || (reg_coef != 0.f && !w))
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_WGRAD), conv_flops(&c), (hipStream_t)stream);
+    return conv_wgrad_bf16_impl(&c, (const __bf16*)dy, lddy, (const __bf16*)x, ldx, dw, reg_coef, w, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* fp32 master weights [N][T][C] -> bf16 work copies: same orientation with the channel dimension padded to Cp, and
+ * transposed [C][T][Np] with the row dimension padded to Np (pad entries are written as zero by the first; the second
+ * leaves columns >= N untouched: pre-zero the buffer once). */
+int unetrir_cast_weight_bf16(const float* w, unetrir_bf16* o, int N, int T, int C, int Cp, unetrir_stream_t stream) {
+    if (!w || !o || N <= 0 || T <= 0 || C <= 0 || Cp < C) return UNETRIR_EINVAL;
+    return launch_cast_weight(w, o, N, T, C, Cp, (hipStream_t)stream);
+}
+
+int unetrir_transpose_cast_weight_bf16(const float* w, unetrir_bf16* wt, int N, int T, int C, int Np, unetrir_stream_t stream) {
+    if (!w || !wt || N <= 0 || T <= 0 || C <= 0 || Np < N) return UNETRIR_EINVAL;
+    return launch_transpose_cast_weight(w, wt, N, T, C, Np, (hipStream_t)stream);
 }
 
 int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C, unetrir_stream_t stream) {

@@ -8,6 +8,20 @@
 #include <math.h>
 #include "kernels.h"
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// 4 consecutive channels as float4, for fp32 (16-byte access) and bf16 (8-byte access) tensors
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+    bf16x4_t o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4_t*>(p) = o;
+}
+
 namespace {
 
 struct ChanPlan { int QB, RB, ngroups, nslab; long long rows_per_slab; };
@@ -39,9 +53,9 @@ inline ChanPlan chan_plan(long long P, int C) {
 //                                               MODE 2: (sum g, sum g*xhat) with g = da*[relu mask]
 // partial layout: double part[nslab][C][2]
 // -------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, int ldx,
-                                                           const float* __restrict__ da, int ldda,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__ x, int ldx,
+                                                           const T* __restrict__ da, int ldda,
                                                            const float* __restrict__ affine,
                                                            const float* __restrict__ saved, int relu,
                                                            long long P, int C, int QB, long long rows_per_slab,
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
     }
     if (cok) {
         for (long long p = p0 + rl; p < p1; p += RB) {
-            const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ldx + c0);
+            const float4 v = ld4(x + (size_t)p * ldx + c0);
             const float xv[4] = {v.x, v.y, v.z, v.w};
             if (MODE == 0) {
 #pragma unroll
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
 #pragma unroll
                 for (int k = 0; k < 4; ++k) s0[k] += (double)xv[k];
             } else {
-                const float4 gq = *reinterpret_cast<const float4*>(da + (size_t)p * ldda + c0);
+                const float4 gq = ld4(da + (size_t)p * ldda + c0);
                 const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -169,16 +183,17 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nsla
 }
 
 // y = x*scale + shift (ReLU optional), float4 over [P][C]
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, long long P, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long P, int C,
                                                        const float* __restrict__ affine, int relu,
-                                                       float* __restrict__ y, int ldy) {
+                                                       T* __restrict__ y, int ldy) {
     const int CQ = C / 4;
     const long long total = P * CQ;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / CQ;
         const int c0 = (int)(i - p * CQ) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ldx + c0);
+        const float4 v = ld4(x + (size_t)p * ldx + c0);
         float4 r;
         if (affine) {
             const float4 sc = *reinterpret_cast<const float4*>(affine + c0);
@@ -188,25 +203,26 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             r = v;
         }
         if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-        *reinterpret_cast<float4*>(y + (size_t)p * ldy + c0) = r;
+        st4(y + (size_t)p * ldy + c0, r);
     }
 }
 
 // dx = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = da * relu-mask;  without BN (affine == NULL): dx = g
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, int ldda,
-                                                           const float* __restrict__ x, int ldx, long long P, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, int ldda,
+                                                           const T* __restrict__ x, int ldx, long long P, int C,
                                                            const float* __restrict__ affine,
                                                            const float* __restrict__ saved,
                                                            const float* __restrict__ coef, int relu,
-                                                           float* __restrict__ dx, int lddx) {
+                                                           T* __restrict__ dx, int lddx) {
     const int CQ = C / 4;
     const long long total = P * CQ;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / CQ;
         const int c0 = (int)(i - p * CQ) * 4;
-        const float4 xv4 = *reinterpret_cast<const float4*>(x + (size_t)p * ldx + c0);
-        const float4 gv4 = *reinterpret_cast<const float4*>(da + (size_t)p * ldda + c0);
+        const float4 xv4 = ld4(x + (size_t)p * ldx + c0);
+        const float4 gv4 = ld4(da + (size_t)p * ldda + c0);
         const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
         const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
         float out[4];
@@ -223,20 +239,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) out[k] = (relu && !(xv[k] > 0.f)) ? 0.f : gv[k];
         }
-        *reinterpret_cast<float4*>(dx + (size_t)p * lddx + c0) = make_float4(out[0], out[1], out[2], out[3]);
+        st4(dx + (size_t)p * lddx + c0, make_float4(out[0], out[1], out[2], out[3]));
     }
 }
 
 // -------------------------------------------------------------------------------------------
 // boundary: NCHW [B,C,H,W] -> NHWC [B,H,W,Cpad] (zero fill), one thread per pixel
 // -------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int C, int H, int W,
-                                        float* __restrict__ y, int Cpad) {
+                                        T* __restrict__ y, int Cpad) {
     const long long hw = (long long)H * W, total = (long long)B * hw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / hw, r = i - b * hw;
-        for (int c = 0; c < Cpad; ++c) y[i * Cpad + c] = (c < C) ? x[(b * C + c) * hw + r] : 0.f;
+        for (int c = 0; c < Cpad; ++c) y[i * Cpad + c] = (T)((c < C) ? x[(b * C + c) * hw + r] : 0.f);
     }
 }
 
@@ -245,10 +262,11 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int 
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
+template <typename T>
 __global__ __launch_bounds__(256) void sigmoid_loss_kernel(const float* __restrict__ logits, int ldl,
                                                            const float* __restrict__ target, int B, int H, int W,
                                                            float alpha, float inv_norm, float* __restrict__ pred,
-                                                           float* __restrict__ dlogits, double* __restrict__ part) {
+                                                           T* __restrict__ dlogits, int ldd, double* __restrict__ part) {
     __shared__ double red[256 * 2];
     const long long hw = (long long)H * W, total = (long long)B * hw;
     const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
@@ -269,8 +287,8 @@ __global__ __launch_bounds__(256) void sigmoid_loss_kernel(const float* __restri
             sp += (double)(1.f - cosf(ph));
             const float g0 = -2.f * da * alpha * inv_norm;
             const float g1 = -(1.f - alpha) * inv_norm * TWO_PI * sinf(ph);
-            *reinterpret_cast<float4*>(dlogits + i * 4) =
-                make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f);
+            st4(dlogits + i * ldd, make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f));
+            if (ldd > 4) st4(dlogits + i * ldd + 4, make_float4(0.f, 0.f, 0.f, 0.f));
         }
     }
     red[threadIdx.x * 2] = sa; red[threadIdx.x * 2 + 1] = sp;
@@ -302,15 +320,17 @@ __global__ void sigmoid_only_kernel(const float* __restrict__ logits, int ldl, i
     }
 }
 
+template <typename T>
 __global__ void sigmoid_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ dpred, int B, int H,
-                                   int W, float* __restrict__ dlogits) {
+                                   int W, T* __restrict__ dlogits, int ldd) {
     const long long hw = (long long)H * W, total = (long long)B * hw;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / hw, r = i - b * hw;
         const float p0 = pred[(b * 2 + 0) * hw + r], p1 = pred[(b * 2 + 1) * hw + r];
         const float g0 = dpred[(b * 2 + 0) * hw + r], g1 = dpred[(b * 2 + 1) * hw + r];
-        *reinterpret_cast<float4*>(dlogits + i * 4) = make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f);
+        st4(dlogits + i * ldd, make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f));
+        if (ldd > 4) st4(dlogits + i * ldd + 4, make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
 
@@ -409,6 +429,78 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096
 }
 static inline bool chan_ok(const void* x, int ld, long long P, int C) { return x && P > 0 && C > 0 && (C & 3) == 0 && ld >= C && (ld & 3) == 0; }
 
+namespace {
+
+template <typename T>
+int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps, float momentum,
+                  float* moving_mean, float* moving_var, float* affine, float* saved, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!chan_ok(x, ldx, P, C) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C);
+    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
+                       beta, eps, momentum, moving_mean, moving_var, affine, saved);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int bn_apply_impl(const T* x, int ldx, long long P, int C, const float* affine, int relu, T* y, int ldy, hipStream_t s) {
+    if (!chan_ok(x, ldx, P, C) || !y || ldy < C || (ldy & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, x, ldx, P, C, affine, relu, y, ldy);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, const float* affine, const float* saved,
+                int relu, T* dx, int lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3) || !affine || !saved || !ws ||
+        ws_bytes < unetrir_bn_ws_bytes(P, C))
+        return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C);
+    double* part = (double*)ws;
+    float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
+    hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
+                       relu, P, C, pl.QB, pl.rows_per_slab, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
+                       (const float*)coef, relu, dx, lddx);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!chan_ok(x, ldx, P, C) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C);
+    hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, C, out);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int relu_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, T* dx, int lddx, hipStream_t s) {
+    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1, dx, lddx);
+    return (int)hipGetLastError();
+}
+
+#define LOSS_BLOCKS 1024
+template <typename T>
+int sigmoid_loss_impl(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha, float inv_norm,
+                      float* pred, T* dlogits, int ldd, float* loss_out, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!logits || ldl < 2 || !target || !pred || !dlogits || !loss_out || !ws || ws_bytes < (size_t)LOSS_BLOCKS * 2 * sizeof(double) ||
+        B <= 0 || H <= 0 || W <= 0 || (ldd != 4 && ldd != 8))
+        return UNETRIR_EINVAL;
+    const unsigned nb = grid_for((long long)B * H * W, 256, LOSS_BLOCKS);
+    hipLaunchKernelGGL(sigmoid_loss_kernel<T>, dim3(nb), dim3(256), 0, s, logits, ldl, target, B, H, W, alpha, inv_norm, pred,
+                       dlogits, ldd, (double*)ws);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, alpha, inv_norm, loss_out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
 extern "C" {
 
 size_t unetrir_bn_ws_bytes(long long P, int C) {
@@ -420,53 +512,25 @@ size_t unetrir_bn_ws_bytes(long long P, int C) {
 int unetrir_bn_stats_f32(const float* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps,
                          float momentum, float* moving_mean, float* moving_var, float* affine, float* saved, void* ws,
                          size_t ws_bytes, unetrir_stream_t stream) {
-    if (!chan_ok(x, ldx, P, C) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
-    const ChanPlan pl = chan_plan(P, C);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const float*)nullptr, 0,
-                       (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
-                       beta, eps, momentum, moving_mean, moving_var, affine, saved);
-    return (int)hipGetLastError();
+    return bn_stats_impl<float>(x, ldx, P, C, gamma, beta, eps, momentum, moving_mean, moving_var, affine, saved, ws, ws_bytes,
+                                (hipStream_t)stream);
 }
 
 int unetrir_bn_apply_f32(const float* x, int ldx, long long P, int C, const float* affine, int relu, float* y, int ldy,
                          unetrir_stream_t stream) {
-    if (!chan_ok(x, ldx, P, C) || !y || ldy < C || (ldy & 3)) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, P, C, affine,
-                       relu, y, ldy);
-    return (int)hipGetLastError();
+    return bn_apply_impl<float>(x, ldx, P, C, affine, relu, y, ldy, (hipStream_t)stream);
 }
 
 int unetrir_bn_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C, const float* gamma,
                        const float* affine, const float* saved, int relu, float* dx, int lddx, float* dgamma,
                        float* dbeta, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
     (void)gamma;
-    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3) || !affine || !saved || !ws ||
-        ws_bytes < unetrir_bn_ws_bytes(P, C))
-        return UNETRIR_EINVAL;
-    const ChanPlan pl = chan_plan(P, C);
-    hipStream_t s = (hipStream_t)stream;
-    double* part = (double*)ws;
-    float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
-    hipLaunchKernelGGL(chan_partial_kernel<2>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
-                       relu, P, C, pl.QB, pl.rows_per_slab, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part, pl.nslab, P, C,
-                       dgamma, dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
-                       (const float*)coef, relu, dx, lddx);
-    return (int)hipGetLastError();
+    return bn_bwd_impl<float>(da, ldda, x, ldx, P, C, affine, saved, relu, dx, lddx, dgamma, dbeta, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int unetrir_colsum_f32(const float* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes,
                        unetrir_stream_t stream) {
-    if (!chan_ok(x, ldx, P, C) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
-    const ChanPlan pl = chan_plan(P, C);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const float*)nullptr, 0,
-                       (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, C, out);
-    return (int)hipGetLastError();
+    return colsum_impl<float>(x, ldx, P, C, out, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int unetrir_relu_fwd_f32(const float* x, int ldx, long long P, int C, float* y, int ldy, unetrir_stream_t stream) {
@@ -475,34 +539,23 @@ int unetrir_relu_fwd_f32(const float* x, int ldx, long long P, int C, float* y, 
 
 int unetrir_relu_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C, float* dx, int lddx,
                          unetrir_stream_t stream) {
-    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3)) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda, x, ldx,
-                       P, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1, dx, lddx);
-    return (int)hipGetLastError();
+    return relu_bwd_impl<float>(da, ldda, x, ldx, P, C, dx, lddx, (hipStream_t)stream);
 }
 
 int unetrir_nchw_to_nhwc_pad_f32(const float* x, int B, int C, int H, int W, float* y, int Cpad, unetrir_stream_t stream) {
     if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B,
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<float>, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B,
                        C, H, W, y, Cpad);
     return (int)hipGetLastError();
 }
 
-#define LOSS_BLOCKS 1024
 size_t unetrir_loss_ws_bytes(long long npix) { (void)npix; return (size_t)LOSS_BLOCKS * 2 * sizeof(double); }
 
 int unetrir_sigmoid_loss_f32(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha,
                              float inv_norm, float* pred, float* dlogits, float* loss_out, void* ws, size_t ws_bytes,
                              unetrir_stream_t stream) {
-    if (!logits || ldl < 2 || !target || !pred || !dlogits || !loss_out || !ws || ws_bytes < unetrir_loss_ws_bytes(0) ||
-        B <= 0 || H <= 0 || W <= 0)
-        return UNETRIR_EINVAL;
-    const unsigned nb = grid_for((long long)B * H * W, 256, LOSS_BLOCKS);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sigmoid_loss_kernel, dim3(nb), dim3(256), 0, s, logits, ldl, target, B, H, W, alpha, inv_norm, pred,
-                       dlogits, (double*)ws);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, alpha, inv_norm, loss_out);
-    return (int)hipGetLastError();
+    return sigmoid_loss_impl<float>(logits, ldl, target, B, H, W, alpha, inv_norm, pred, dlogits, 4, loss_out, ws, ws_bytes,
+                                    (hipStream_t)stream);
 }
 
 int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, float* pred, unetrir_stream_t stream) {
@@ -515,8 +568,8 @@ int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, 
 int unetrir_sigmoid_bwd_f32(const float* pred, const float* dpred, int B, int H, int W, float* dlogits,
                             unetrir_stream_t stream) {
     if (!pred || !dpred || !dlogits || B <= 0 || H <= 0 || W <= 0) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, pred, dpred,
-                       B, H, W, dlogits);
+    hipLaunchKernelGGL(sigmoid_bwd_kernel<float>, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, pred,
+                       dpred, B, H, W, dlogits, 4);
     return (int)hipGetLastError();
 }
 
@@ -557,6 +610,90 @@ int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long
     if (!theta || !g || !m || !v || n <= 0) return UNETRIR_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n,
                        lr_t, beta1, beta2, eps, grad_scale);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// -------------------------------------------------------------------------------------------
+// bf16-storage variants (activations bf16, statistics / parameters fp32) and the fp32 <-> bf16 glue of the
+// information-vector branch, which stays fp32
+// -------------------------------------------------------------------------------------------
+__global__ void add_f32_to_bf16_kernel(const __bf16* __restrict__ a, const float* __restrict__ b, __bf16* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ld4(a + i * 4), v = ld4(b + i * 4);
+        st4(y + i * 4, make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w));
+    }
+}
+
+__global__ void cast_bf16_to_f32_kernel(const __bf16* __restrict__ a, float* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        st4(y + i * 4, ld4(a + i * 4));
+}
+
+extern "C" {
+
+int unetrir_bn_stats_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps,
+                          float momentum, float* moving_mean, float* moving_var, float* affine, float* saved, void* ws,
+                          size_t ws_bytes, unetrir_stream_t stream) {
+    return bn_stats_impl<__bf16>((const __bf16*)x, ldx, P, C, gamma, beta, eps, momentum, moving_mean, moving_var, affine, saved, ws,
+                                 ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_bn_apply_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* affine, int relu, unetrir_bf16* y, int ldy,
+                          unetrir_stream_t stream) {
+    return bn_apply_impl<__bf16>((const __bf16*)x, ldx, P, C, affine, relu, (__bf16*)y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_bn_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x, int ldx, long long P, int C, const float* affine,
+                        const float* saved, int relu, unetrir_bf16* dx, int lddx, float* dgamma, float* dbeta, void* ws,
+                        size_t ws_bytes, unetrir_stream_t stream) {
+    return bn_bwd_impl<__bf16>((const __bf16*)da, ldda, (const __bf16*)x, ldx, P, C, affine, saved, relu, (__bf16*)dx, lddx, dgamma,
+                               dbeta, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_colsum_bf16(const unetrir_bf16* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes,
+                        unetrir_stream_t stream) {
+    return colsum_impl<__bf16>((const __bf16*)x, ldx, P, C, out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_relu_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x, int ldx, long long P, int C, unetrir_bf16* dx,
+                          int lddx, unetrir_stream_t stream) {
+    return relu_bwd_impl<__bf16>((const __bf16*)da, ldda, (const __bf16*)x, ldx, P, C, (__bf16*)dx, lddx, (hipStream_t)stream);
+}
+
+int unetrir_nchw_to_nhwc_pad_bf16(const float* x, int B, int C, int H, int W, unetrir_bf16* y, int Cpad, unetrir_stream_t stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < C) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<__bf16>, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, x, B,
+                       C, H, W, (__bf16*)y, Cpad);
+    return (int)hipGetLastError();
+}
+
+int unetrir_sigmoid_loss_bf16(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha, float inv_norm,
+                              float* pred, unetrir_bf16* dlogits, float* loss_out, void* ws, size_t ws_bytes,
+                              unetrir_stream_t stream) {
+    return sigmoid_loss_impl<__bf16>(logits, ldl, target, B, H, W, alpha, inv_norm, pred, (__bf16*)dlogits, 8, loss_out, ws, ws_bytes,
+                                     (hipStream_t)stream);
+}
+
+int unetrir_sigmoid_bwd_bf16(const float* pred, const float* dpred, int B, int H, int W, unetrir_bf16* dlogits,
+                             unetrir_stream_t stream) {
+    if (!pred || !dpred || !dlogits || B <= 0 || H <= 0 || W <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel<__bf16>, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, pred,
+                       dpred, B, H, W, (__bf16*)dlogits, 8);
+    return (int)hipGetLastError();
+}
+
+int unetrir_add_f32_to_bf16(const unetrir_bf16* a, const float* b, unetrir_bf16* y, long long n, unetrir_stream_t stream) {
+    if (!a || !b || !y || n <= 0 || (n & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(add_f32_to_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, b,
+                       (__bf16*)y, n / 4);
+    return (int)hipGetLastError();
+}
+
+int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetrir_stream_t stream) {
+    if (!a || !y || n <= 0 || (n & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, y, n / 4);
     return (int)hipGetLastError();
 }
 

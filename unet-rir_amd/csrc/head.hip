@@ -11,9 +11,22 @@
 #define HP (HT + HK - 1)      // 21: patch edge
 #define HPAD_T 2              // TF SAME for k=6, s=1: pad (2, 3)
 
+typedef __bf16 bf16x4_h __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ld4h(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4h(const __bf16* p) {
+    const bf16x4_h v = *reinterpret_cast<const bf16x4_h*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ float2 ld2h(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2h(const __bf16* p) {
+    const bf16x2_h v = *reinterpret_cast<const bf16x2_h*>(p);
+    return make_float2((float)v[0], (float)v[1]);
+}
+
 // stage channels [c0, c0+CC) of the patch around tile (ty0, tx0) of image n into LDS, zero outside the image
-template <int CC>
-__device__ __forceinline__ void load_patch(const float* __restrict__ x, int ldx, int H, int W, int n, int ty0, int tx0,
+template <int CC, typename T>
+__device__ __forceinline__ void load_patch(const T* __restrict__ x, int ldx, int H, int W, int n, int ty0, int tx0,
                                            int c0, float* __restrict__ As) {
     constexpr int Q = CC / 4, LD = CC + 4;
     for (int i = threadIdx.x; i < HP * HP * Q; i += 256) {
@@ -22,14 +35,14 @@ __device__ __forceinline__ void load_patch(const float* __restrict__ x, int ldx,
         const int iy = ty0 + py - HPAD_T, ix = tx0 + px - HPAD_T;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = *reinterpret_cast<const float4*>(x + ((size_t)((long long)n * H + iy) * W + ix) * ldx + c0 + q * 4);
+            v = ld4h(x + ((size_t)((long long)n * H + iy) * W + ix) * ldx + c0 + q * 4);
         *reinterpret_cast<float4*>(&As[pix * LD + q * 4]) = v;
     }
 }
 
 // forward: y[p][0..1] = bias + sum_t sum_c x[p + off_t][c] * w[n][t][c]; y is [P][ldy] (ldy >= 2), channels 2.. zeroed up to 4
-template <int CC>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, int ldx, int B, int H, int W, int C,
+template <int CC, typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int ldx, int B, int H, int W, int C,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ y, int ldy) {
     constexpr int LD = CC + 4;
@@ -44,7 +57,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     const int ldw = HK * HK * C;
     for (int c0 = 0; c0 < C; c0 += CC) {
         if (c0) __syncthreads();
-        load_patch<CC>(x, ldx, H, W, n, ty0, tx0, c0, As);
+        load_patch<CC, T>(x, ldx, H, W, n, ty0, tx0, c0, As);
         __syncthreads();
 #pragma unroll 1
         for (int kh = 0; kh < HK; ++kh) {
@@ -77,9 +90,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
 // weight gradient: part[blk][n][t][c] = sum over the block's tiles of dy[p][n] * x[p + off_t][c]
 // thread = (channel c in the CC-chunk, tap group g); tap t belongs to group t % NG
-template <int CC>
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, int ldx, int B, int H, int W, int C,
-                                                         const float* __restrict__ dy, int lddy,
+template <int CC, typename T>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x, int ldx, int B, int H, int W, int C,
+                                                         const T* __restrict__ dy, int lddy,
                                                          float* __restrict__ part, int ntiles_total) {
     constexpr int LD = CC + 4, NG = 256 / CC, TPG = (HK * HK + NG - 1) / NG;
     __shared__ __attribute__((aligned(16))) float As[HP * HP * LD];
@@ -100,12 +113,12 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
         const int r = tile - n * tilesx * tilesy;
         const int ty0 = (r / tilesx) * HT, tx0 = (r % tilesx) * HT;
         __syncthreads();
-        load_patch<CC>(x, ldx, H, W, n, ty0, tx0, c0, As);
+        load_patch<CC, T>(x, ldx, H, W, n, ty0, tx0, c0, As);
         {
             const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15;
             const int oy = ty0 + ly, ox = tx0 + lx;
             float2 d = make_float2(0.f, 0.f);
-            if (oy < H && ox < W) d = *reinterpret_cast<const float2*>(dy + (((size_t)n * H + oy) * W + ox) * lddy);
+            if (oy < H && ox < W) d = ld2h(dy + (((size_t)n * H + oy) * W + ox) * lddy);
             Ds[threadIdx.x] = d;
         }
         __syncthreads();
@@ -135,45 +148,61 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 
 #define HEAD_WGRAD_BLOCKS 512
 
+namespace {
+
+template <typename T>
+int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 16) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
+        return UNETRIR_EINVAL;
+    const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
+    if (C % 32 == 0) hipLaunchKernelGGL((head_fwd_kernel<32, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
+    else hipLaunchKernelGGL((head_fwd_kernel<16, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy, int lddy, float* dw, void* ws, size_t ws_bytes,
+                    hipStream_t s) {
+    if (!x || !dy || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 16) || ldx < C || (ldx & 3) || lddy < 2 || (lddy & 1) ||
+        ws_bytes < (size_t)HEAD_WGRAD_BLOCKS * 2 * HK * HK * C * sizeof(float))
+        return UNETRIR_EINVAL;
+    const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
+    const int nblk = tiles < HEAD_WGRAD_BLOCKS ? (int)tiles : HEAD_WGRAD_BLOCKS;
+    if (C % 32 == 0)
+        hipLaunchKernelGGL((head_wgrad_kernel<32, T>), dim3(nblk, C / 32), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws, (int)tiles);
+    else
+        hipLaunchKernelGGL((head_wgrad_kernel<16, T>), dim3(nblk, C / 16), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws, (int)tiles);
+    const size_t nout = (size_t)2 * HK * HK * C;
+    return launch_splitk_reduce((const float*)ws, nblk, nout, dw, 0.f, nullptr, s);
+}
+
+}  // namespace
+
 extern "C" {
 
 int unetrir_head6x6_supported(int C) { return (C % 16) == 0 ? 1 : 0; }
 
-// Conv2D(2, (6,6), 'same') forward: x [B,H,W,C] (ldx), w [>=2][6][6][C] (rows 0,1 used), y [P][ldy]; with ldy >= 4 channels 2,3 are written as zero.
 int unetrir_head6x6_fwd_f32(const float* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y,
                             int ldy, unetrir_stream_t stream) {
-    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 16) || ldx < C || (ldx & 3) || ldy < 2 ||
-        (ldy >= 4 && (ldy & 3)))
-        return UNETRIR_EINVAL;
-    const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
-    if (C % 32 == 0)
-        hipLaunchKernelGGL(head_fwd_kernel<32>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, ldx, B, H, W, C, w,
-                           bias, y, ldy);
-    else
-        hipLaunchKernelGGL(head_fwd_kernel<16>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, x, ldx, B, H, W, C, w,
-                           bias, y, ldy);
-    return (int)hipGetLastError();
+    return head_fwd_impl<float>(x, ldx, B, H, W, C, w, bias, y, ldy, (hipStream_t)stream);
 }
 
 size_t unetrir_head6x6_wgrad_ws_bytes(int C) { return (size_t)HEAD_WGRAD_BLOCKS * 2 * HK * HK * C * sizeof(float); }
 
-// dw[0..1][6][6][C] = sum_pixels dy[p][0..1] * x[p + off][c]  (rows 2.. of a padded kernel are left untouched)
 int unetrir_head6x6_wgrad_f32(const float* x, int ldx, int B, int H, int W, int C, const float* dy, int lddy, float* dw,
                               void* ws, size_t ws_bytes, unetrir_stream_t stream) {
-    if (!x || !dy || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 16) || ldx < C || (ldx & 3) || lddy < 2 ||
-        (lddy & 1) || ws_bytes < unetrir_head6x6_wgrad_ws_bytes(C))
-        return UNETRIR_EINVAL;
-    const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
-    const int nblk = tiles < HEAD_WGRAD_BLOCKS ? (int)tiles : HEAD_WGRAD_BLOCKS;
-    hipStream_t s = (hipStream_t)stream;
-    if (C % 32 == 0)
-        hipLaunchKernelGGL(head_wgrad_kernel<32>, dim3(nblk, C / 32), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws,
-                           (int)tiles);
-    else
-        hipLaunchKernelGGL(head_wgrad_kernel<16>, dim3(nblk, C / 16), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws,
-                           (int)tiles);
-    const size_t nout = (size_t)2 * HK * HK * C;
-    return launch_splitk_reduce((const float*)ws, nblk, nout, dw, 0.f, nullptr, s);
+    return head_wgrad_impl<float>(x, ldx, B, H, W, C, dy, lddy, dw, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* bf16 activations in, fp32 logits / fp32 weight gradient out */
+int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y,
+                             int ldy, unetrir_stream_t stream) {
+    return head_fwd_impl<__bf16>((const __bf16*)x, ldx, B, H, W, C, w, bias, y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy, int lddy,
+                               float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    return head_wgrad_impl<__bf16>((const __bf16*)x, ldx, B, H, W, C, (const __bf16*)dy, lddy, dw, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,397 @@
+// igemm_bf16.hip - bf16-storage / fp32-accumulate variants of the implicit-GEMM convolution kernels (gfx950).
+//
+// Same tap-table formulation as igemm.hip; activations and the weight work copies are bf16, accumulation is fp32 in
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate), bias / BatchNorm parameters / weight gradients stay fp32.
+//   forward-type kernel : A = activations [pixel][k], B = weights [n][k], both K-contiguous -> one ds_read_b128 per
+//                         operand per MFMA (lane l holds k = 8*(l>>5) .. +7 of row l&31).
+//   3x3 weight gradient : K = pixels, which is the STRIDED dimension of NHWC tiles; the operands come out of LDS
+//                         through ds_read_b64_tr_b16 (hardware 4x16 transpose), two reads per operand.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BKH 64            // bf16 k-values per LDS stage (128 B per row, as the fp32 kernel)
+#define LDH 72            // padded row length in bf16 elements (144 B = 9 x 16 B)
+
+__device__ __forceinline__ int xcd_remap_h(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward-type kernel (Conv2D fwd, Conv2DTranspose fwd, every data gradient)
+// ------------------------------------------------------------------------------------------------
+template <int BN_, bool UNIFORM>
+__global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a) {
+    constexpr int NSUB = BN_ / 64;
+    constexpr int NB = BN_ / 32;
+    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN_ * LDH];
+    __shared__ uint32_t s_tap[UNETRIR_MAX_TAPS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    if (tid < UNETRIR_MAX_TAPS) s_tap[tid] = a.g.tap[tid];
+
+    const int ntN = (a.g.N + BN_ - 1) / BN_;
+    const int id = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int mt = id / ntN, nt = id - mt * ntN;
+    const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN_;
+
+    const int C = a.g.C, ntaps = a.g.ntaps;
+    const int IH = a.g.IH, IW = a.g.IW, ldi = a.g.ldi;
+    const int ldw = a.g.wtaps * C;
+    const int nch = (ntaps * C + BKH - 1) / BKH;
+
+    const int quad = tid & 7, lrow = tid >> 3;          // 8 threads x 8 bf16 = one 64-wide row; 32 rows per pass
+    int kt = UNIFORM ? 0 : (quad * 8) / C;
+    int kc = UNIFORM ? 0 : (quad * 8) % C;
+    __syncthreads();
+
+    const __bf16* a_ptr[4];
+    unsigned long long a_mask[4];
+    const int plane = a.g.PH * a.g.PW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = m0 + lrow + 32 * j;
+        a_ptr[j] = a.in;
+        a_mask[j] = 0ull;
+        if (p < M) {
+            const int n = (int)(p / plane);
+            const int rem = (int)(p - (long long)n * plane);
+            const int py = rem / a.g.PW, px = rem - py * a.g.PW;
+            const int by = py * a.g.SI, bx = px * a.g.SI;
+            a_ptr[j] = a.in + ((long long)((long long)n * IH + by) * IW + bx) * ldi;
+            unsigned long long m = 0ull;
+            for (int t = 0; t < ntaps; ++t) {
+                const uint32_t e = s_tap[t];
+                const int iy = by + (int)(int8_t)(e & 0xff), ix = bx + (int)(int8_t)((e >> 8) & 0xff);
+                if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) m |= 1ull << t;
+            }
+            a_mask[j] = m;
+        }
+    }
+    const __bf16* b_ptr[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + lrow + 32 * j;
+        b_ok[j] = n < a.g.N;
+        b_ptr[j] = a.w + (size_t)(b_ok[j] ? n : 0) * ldw;
+    }
+
+    uint4 ra[4], rb[NB];
+    auto load_stage = [&]() {
+        int t = kt, c = kc;
+        if (UNIFORM) { t = __builtin_amdgcn_readfirstlane(t); c = __builtin_amdgcn_readfirstlane(c); }
+        const bool kok = t < ntaps;
+        uint32_t e = kok ? s_tap[t] : 0u;
+        if (UNIFORM) e = __builtin_amdgcn_readfirstlane(e);
+        const int dy = (int)(int8_t)(e & 0xff), dx = (int)(int8_t)((e >> 8) & 0xff);
+        const int wi = (int)((e >> 16) & 0xff);
+        const int aoff = (dy * IW + dx) * ldi + c + (UNIFORM ? quad * 8 : 0);
+        const int boff = wi * C + c + (UNIFORM ? quad * 8 : 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kok && ((a_mask[j] >> t) & 1ull)) v = *reinterpret_cast<const uint4*>(a_ptr[j] + aoff);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (kok && b_ok[j]) v = *reinterpret_cast<const uint4*>(b_ptr[j] + boff);
+            rb[j] = v;
+        }
+    };
+
+    f32x16 acc[2][NSUB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_stage();
+    const int arow = wm * 64 + (lane & 31), brow = wn * (BN_ / 2) + (lane & 31);
+    const int koff = (lane >> 5) * 8;
+
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&As[(lrow + 32 * j) * LDH + quad * 8]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(&Bs[(lrow + 32 * j) * LDH + quad * 8]) = rb[j];
+        __syncthreads();
+        if (ch + 1 < nch) {
+            kc += BKH;
+            while (kc >= C) { kc -= C; ++kt; }
+            load_stage();
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[NSUB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&As[(arow + 32 * i) * LDH + kk * 16 + koff]);
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&Bs[(brow + 32 * j) * LDH + kk * 16 + koff]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const bool simple = (a.g.SO == 1 && a.g.ooy == 0 && a.g.oox == 0 && a.g.OH == a.g.PH && a.g.OW == a.g.PW);
+    float bias[NSUB];
+    int ncol[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+        ncol[j] = n0 + wn * (BN_ / 2) + 32 * j + (lane & 31);
+        bias[j] = (a.bias != nullptr && ncol[j] < a.g.N) ? a.bias[ncol[j]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const long long p = m0 + row;
+            if (p >= M) continue;
+            long long opix;
+            if (simple) {
+                opix = p;
+            } else {
+                const int n = (int)(p / plane);
+                const int rem = (int)(p - (long long)n * plane);
+                const int py = rem / a.g.PW, px = rem - py * a.g.PW;
+                const int oy = py * a.g.SO + a.g.ooy, ox = px * a.g.SO + a.g.oox;
+                if (oy >= a.g.OH || ox >= a.g.OW) continue;
+                opix = ((long long)n * a.g.OH + oy) * a.g.OW + ox;
+            }
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+                if (ncol[j] < a.g.N) {
+                    float v = acc[i][j][r] + bias[j];
+                    if (a.addend != nullptr) v += (float)a.addend[opix * a.ldadd + ncol[j]];
+                    a.out[opix * a.g.ldo + ncol[j]] = (__bf16)v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 weight gradient, bf16 operands, fp32 partial slabs (see wgrad3x3.hip for the patch scheme)
+// ------------------------------------------------------------------------------------------------
+#define TPW 8
+
+template <int SI, int TPH>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH a) {
+    constexpr int XH = (TPH - 1) * SI + 3, XW = (TPW - 1) * SI + 3;
+    constexpr int XN = XH * XW * 8;                  // 16-byte slots of the x patch (8 per pixel: 64 channels)
+    constexpr int XJ = (XN + 255) / 256;
+    constexpr int DN = TPH * TPW * 8;                // 16-byte slots of the dy patch
+    constexpr int DJ = (DN + 255) / 256;
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[XH * XW * LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[TPH * TPW * LDH];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int ntC = (a.C + 63) / 64;
+    const int rt = blockIdx.x / ntC, ct = blockIdx.x - rt * ntC;
+    const int n0 = rt * 64, c0 = ct * 64;
+    const int per_img = a.npy * a.npx;
+    const int G = a.B * per_img;
+    const int g0 = blockIdx.y * a.patches_per_split;
+    int g1 = g0 + a.patches_per_split;
+    if (g1 > G) g1 = G;
+
+    uint4 rx[XJ], rd[DJ];
+    const int q8 = tid & 7;
+    const bool cok = (c0 + q8 * 8) < a.C, nok = (n0 + q8 * 8) < a.N;
+
+    auto load_patch = [&](int g) {
+        const int img = g / per_img;
+        const int rem = g - img * per_img;
+        const int pyi = rem / a.npx, pxi = rem - pyi * a.npx;
+        const int py0 = pyi * TPH, px0 = pxi * TPW;
+        const int iy0 = py0 * SI - a.pad_t, ix0 = px0 * SI - a.pad_l;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int i = tid + 256 * j;
+            const int pp = i >> 3;
+            const int pr = pp / XW, pc = pp - pr * XW;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < XN && cok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW)
+                v = *reinterpret_cast<const uint4*>(a.x + ((size_t)((long long)img * a.IH + iy) * a.IW + ix) * a.ldx + c0 + q8 * 8);
+            rx[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            const int i = tid + 256 * j;
+            const int pix = i >> 3;
+            const int oy = py0 + (pix >> 3), ox = px0 + (pix & 7);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < DN && nok && oy < a.OH && ox < a.OW)
+                v = *reinterpret_cast<const uint4*>(a.dy + ((size_t)((long long)img * a.OH + oy) * a.OW + ox) * a.lddy + n0 + q8 * 8);
+            rd[j] = v;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ds_read_b64_tr_b16: inside each 16-lane group lane 4q+p supplies the address of LDS-matrix row q (a pixel),
+    // columns 4p..4p+3 (channels); lane i of the group receives column i of the 4 rows.  Operand lane l wants
+    // channel (l&31) and pixels 8*(l>>5)+j: groups 0/1 cover channels 0-15/16-31 of the low k half, 2/3 the high half.
+    const int grp = lane >> 4, li = lane & 15;
+    const int tq = li >> 2, tp = li & 3;
+    const int chan = (grp & 1) * 16 + tp * 4;
+    // pixel (inside a 16-pixel K step = 2 patch rows of 8) supplied by this lane for read rd: row h, col 4*rd + tq
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const int dlane = (h * 8 + tq) * LDH + wr * 32 + chan;                       // + (s*16 + 4*rd) * LDH
+    const int xlane = ((h * SI) * XW + tq * SI) * LDH + wc * 32 + chan;          // + ((2s*SI + kh) * XW + 4*rd*SI + kw) * LDH
+
+    if (g0 < g1) load_patch(g0);
+    for (int g = g0; g < g1; ++g) {
+        if (g != g0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int i = tid + 256 * j;
+            if (i < XN) *reinterpret_cast<uint4*>(&Xs[(i >> 3) * LDH + q8 * 8]) = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            const int i = tid + 256 * j;
+            if (i < DN) *reinterpret_cast<uint4*>(&Ds[(i >> 3) * LDH + q8 * 8]) = rd[j];
+        }
+        __syncthreads();
+        if (g + 1 < g1) load_patch(g + 1);
+#pragma unroll
+        for (int s = 0; s < TPH / 2; ++s) {
+            bf16x8 fa;
+            {
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ds + dlane + (s * 16) * LDH));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ds + dlane + (s * 16 + 4) * LDH));
+                fa = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t - kh * 3;
+                const int off0 = ((2 * s * SI + kh) * XW + kw) * LDH;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0 + 4 * SI * LDH));
+                const bf16x8 fb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    float* part = a.part + (size_t)blockIdx.y * a.N * 9 * a.C;
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c < a.C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < a.N) part[((size_t)n * 9 + t) * a.C + c] = acc[t][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight work copies: fp32 master [N][T][C] -> bf16 [N][T][Cp] (same orientation, channel pad) and bf16 [C][T][Np]
+// ------------------------------------------------------------------------------------------------
+__global__ void cast_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ o, int N, int T, int C, int Cp) {
+    const size_t total = (size_t)N * T * Cp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const size_t nt = i / Cp;
+        o[i] = (c < C) ? (__bf16)w[nt * C + c] : (__bf16)0.f;
+    }
+}
+
+__global__ void transpose_cast_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ wt, int N, int T, int C, int Np) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, c = c0 + tx;
+        tile[r][tx] = (n < N && c < C) ? w[((size_t)n * T + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, n = n0 + tx;
+        if (n < Np && c < C) wt[((size_t)c * T + t) * Np + n] = (__bf16)tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s) {
+    const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
+    if (M <= 0 || a.g.N <= 0) return 0;
+    const long long mt = (M + BM - 1) / BM;
+    const bool uniform = (a.g.C % BKH) == 0;
+    if (a.g.N > 64) {
+        const long long nwg = mt * ((a.g.N + 127) / 128);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_bf16_kernel<128, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_fwd_bf16_kernel<128, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+    } else {
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_bf16_kernel<64, true>), dim3((unsigned)mt), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_fwd_bf16_kernel<64, false>), dim3((unsigned)mt), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+void wgrad3x3_plan(int stride, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx);
+
+int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    int ns, per;
+    wgrad3x3_plan(stride, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    const size_t nout = (size_t)a.N * 9 * a.C;
+    const bool direct = (ns == 1 && reg == 0.f);
+    if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return UNETRIR_EINVAL;
+    a.part = direct ? dw : (float*)ws;
+    a.patches_per_split = per;
+    const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
+    if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 4>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, 2>), dim3(tiles, ns), dim3(256), 0, s, a);
+    int err = (int)hipGetLastError();
+    if (err || direct) return err;
+    return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);
+}
+
+int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hipStream_t s) {
+    const size_t total = (size_t)N * T * Cp;
+    unsigned nb = (unsigned)((total + 255) / 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(cast_weight_kernel, dim3(nb), dim3(256), 0, s, w, (__bf16*)o, N, T, C, Cp);
+    return (int)hipGetLastError();
+}
+
+int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, int Np, hipStream_t s) {
+    dim3 grid((C + 31) / 32, (Np + 31) / 32, T);
+    hipLaunchKernelGGL(transpose_cast_weight_kernel, grid, dim3(256), 0, s, w, (__bf16*)wt, N, T, C, Np);
+    return (int)hipGetLastError();
+}

@@ -55,3 +55,26 @@ struct Wgrad3Args {
 };
 size_t wgrad3x3_ws_bytes(int stride, int B, int OH, int OW, int N, int C);
 int launch_wgrad3x3(Wgrad3Args a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
+
+// ---- bf16-storage variants (igemm_bf16.hip): activations / weight work copies bf16, accumulate fp32 ----
+struct IgemmArgsH {
+    IgemmGeom g;
+    const __bf16* in;
+    const __bf16* w;       // [N][wtaps][C] bf16
+    const float* bias;     // nullable, fp32
+    const __bf16* addend;  // nullable
+    int ldadd;
+    __bf16* out;
+};
+struct Wgrad3ArgsH {
+    const __bf16* x; int ldx; int IH, IW;
+    const __bf16* dy; int lddy; int OH, OW;
+    int B, C, N;
+    int pad_t, pad_l;
+    float* part;                              // fp32 partial slabs [nsplit][N][9][C]
+    int patches_per_split, npy, npx;
+};
+int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
+int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hipStream_t s);
+int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, int Np, hipStream_t s);

@@ -12,20 +12,22 @@ from ._lib import ConvGeom, check
 
 
 class Act:
-    """An NHWC fp32 activation view: channels [c0, c0+C) of a [B,H,W,ld] device buffer.
+    """An NHWC activation view (fp32 or bf16 storage): channels [c0, c0+C) of a [B,H,W,ld] device buffer.
     A channel-concat (dl_models/u_net.py:308) is two Acts over one buffer."""
-    __slots__ = ("base", "B", "H", "W", "C", "ld", "c0", "ptr")
+    __slots__ = ("base", "B", "H", "W", "C", "ld", "c0", "ptr", "sfx")
 
     def __init__(self, base: torch.Tensor, c0: int = 0, C_: int = None):
-        if base.dim() != 4 or not base.is_contiguous() or base.dtype != torch.float32:
-            raise ValueError("Act needs a contiguous fp32 [B,H,W,ld] tensor")
+        if base.dim() != 4 or not base.is_contiguous() or base.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("Act needs a contiguous fp32 or bf16 [B,H,W,ld] tensor")
         self.base = base
         self.B, self.H, self.W, self.ld = base.shape
         self.c0 = c0
         self.C = self.ld - c0 if C_ is None else C_
-        if self.c0 % 4 or self.ld % 4 or self.c0 + self.C > self.ld:
-            raise ValueError("channel offset and pixel stride must be multiples of 4")
-        self.ptr = base.data_ptr() + 4 * c0
+        self.sfx = "f32" if base.dtype == torch.float32 else "bf16"
+        al = 16 // base.element_size()                    # rows and slices start on 16-byte boundaries
+        if self.c0 % al or self.ld % al or self.c0 + self.C > self.ld:
+            raise ValueError(f"channel offset and pixel stride must be multiples of {al}")
+        self.ptr = base.data_ptr() + base.element_size() * c0
 
     @property
     def P(self):
@@ -39,8 +41,13 @@ class Act:
         return self.base[..., self.c0:self.c0 + self.C].contiguous()
 
 
-def new_act(B, H, W, C_, device, ld=None):
-    return Act(torch.empty((B, H, W, C_ if ld is None else ld), dtype=torch.float32, device=device), 0, C_)
+def new_act(B, H, W, C_, device, ld=None, dtype=torch.float32):
+    return Act(torch.empty((B, H, W, C_ if ld is None else ld), dtype=dtype, device=device), 0, C_)
+
+
+def _fn(name, sfx):
+    """C entry point `unetrir_<name>_<f32|bf16>`."""
+    return getattr(_lib.lib(), f"unetrir_{name}_{sfx}")
 
 
 def _stream():
@@ -83,13 +90,13 @@ class Workspace:
 
 def conv2d_fwd(g, x: Act, w, bias, y: Act, addend: Act = None):
     """Conv2D(padding='same') forward (dl_models/u_net.py:269-276, :366, :248, :262)."""
-    check(_lib.lib().unetrir_conv2d_fwd_f32(C.byref(g), _p(x), x.ld, _p(w), _p(bias), _p(addend),
+    check(_fn("conv2d_fwd", x.sfx)(C.byref(g), _p(x), x.ld, _p(w), _p(bias), _p(addend),
                                             addend.ld if addend is not None else 0, _p(y), y.ld, _stream()),
           "conv2d_fwd")
 
 
 def conv2d_dgrad(g, dy: Act, wt, dx: Act, addend: Act = None):
-    check(_lib.lib().unetrir_conv2d_dgrad_f32(C.byref(g), _p(dy), dy.ld, _p(wt), _p(addend),
+    check(_fn("conv2d_dgrad", dy.sfx)(C.byref(g), _p(dy), dy.ld, _p(wt), _p(addend),
                                               addend.ld if addend is not None else 0, _p(dx), dx.ld, _stream()),
           "conv2d_dgrad")
 
@@ -100,18 +107,18 @@ def conv2d_wgrad_ws_bytes(g):
 
 def conv2d_wgrad(g, x: Act, dy: Act, dw, ws: Workspace, reg=0.0, w=None):
     ws.reserve(conv2d_wgrad_ws_bytes(g))
-    check(_lib.lib().unetrir_conv2d_wgrad_f32(C.byref(g), _p(x), x.ld, _p(dy), dy.ld, _p(dw), float(reg), _p(w),
+    check(_fn("conv2d_wgrad", x.sfx)(C.byref(g), _p(x), x.ld, _p(dy), dy.ld, _p(dw), float(reg), _p(w),
                                               ws.ptr, ws.nbytes, _stream()), "conv2d_wgrad")
 
 
 def conv2d_transpose_fwd(g, x: Act, wt, bias, y: Act):
     """Conv2DTranspose(strides=2, padding='same') forward (dl_models/u_net.py:297-304)."""
-    check(_lib.lib().unetrir_conv2d_transpose_fwd_f32(C.byref(g), _p(x), x.ld, _p(wt), _p(bias), _p(y), y.ld,
+    check(_fn("conv2d_transpose_fwd", x.sfx)(C.byref(g), _p(x), x.ld, _p(wt), _p(bias), _p(y), y.ld,
                                                       _stream()), "conv2d_transpose_fwd")
 
 
 def conv2d_transpose_dgrad(g, dy: Act, w, dx: Act, addend: Act = None):
-    check(_lib.lib().unetrir_conv2d_transpose_dgrad_f32(C.byref(g), _p(dy), dy.ld, _p(w), _p(addend),
+    check(_fn("conv2d_transpose_dgrad", dy.sfx)(C.byref(g), _p(dy), dy.ld, _p(w), _p(addend),
                                                         addend.ld if addend is not None else 0, _p(dx), dx.ld,
                                                         _stream()), "conv2d_transpose_dgrad")
 
@@ -122,7 +129,7 @@ def conv2d_transpose_wgrad_ws_bytes(g):
 
 def conv2d_transpose_wgrad(g, x: Act, dy: Act, dw, ws: Workspace, reg=0.0, w=None):
     ws.reserve(conv2d_transpose_wgrad_ws_bytes(g))
-    check(_lib.lib().unetrir_conv2d_transpose_wgrad_f32(C.byref(g), _p(x), x.ld, _p(dy), dy.ld, _p(dw), float(reg),
+    check(_fn("conv2d_transpose_wgrad", x.sfx)(C.byref(g), _p(x), x.ld, _p(dy), dy.ld, _p(dw), float(reg),
                                                         _p(w), ws.ptr, ws.nbytes, _stream()),
           "conv2d_transpose_wgrad")
 
@@ -130,6 +137,26 @@ def conv2d_transpose_wgrad(g, x: Act, dy: Act, dw, ws: Workspace, reg=0.0, w=Non
 def transpose_weight(w, wt, N, T, C_):
     """[N][T][C] -> [C][T][N]."""
     check(_lib.lib().unetrir_transpose_weight_f32(_p(w), _p(wt), N, T, C_, _stream()), "transpose_weight")
+
+
+def cast_weight_bf16(w, o, N, T, C_, Cp):
+    """fp32 master [N][T][C] -> bf16 [N][T][Cp] (zero-padded channels)."""
+    check(_lib.lib().unetrir_cast_weight_bf16(_p(w), _p(o), N, T, C_, Cp, _stream()), "cast_weight_bf16")
+
+
+def transpose_cast_weight_bf16(w, wt, N, T, C_, Np):
+    """fp32 master [N][T][C] -> bf16 [C][T][Np] (zero-padded rows)."""
+    check(_lib.lib().unetrir_transpose_cast_weight_bf16(_p(w), _p(wt), N, T, C_, Np, _stream()),
+          "transpose_cast_weight_bf16")
+
+
+def add_f32_to_bf16(a: Act, b: Act, y: Act):
+    """y = a + b with a, y bf16 and b fp32, dense buffers (Add() of dl_models/u_net.py:229 in the bf16 trunk)."""
+    check(_lib.lib().unetrir_add_f32_to_bf16(_p(a), _p(b), _p(y), a.base.numel(), _stream()), "add_f32_to_bf16")
+
+
+def cast_bf16_to_f32(a: Act, y: Act):
+    check(_lib.lib().unetrir_cast_bf16_to_f32(_p(a), _p(y), a.base.numel(), _stream()), "cast_bf16_to_f32")
 
 
 # ---- BatchNormalization + ReLU ---------------------------------------------------------------
@@ -142,35 +169,43 @@ def bn_stats(x: Act, gamma, beta, affine, saved, ws: Workspace, moving_mean=None
              eps=1e-3, momentum=0.99):
     """BatchNormalization() batch statistics (dl_models/u_net.py:368)."""
     ws.reserve(bn_ws_bytes(x.P, x.C))
-    check(_lib.lib().unetrir_bn_stats_f32(_p(x), x.ld, x.P, x.C, _p(gamma), _p(beta), eps, momentum,
+    check(_fn("bn_stats", x.sfx)(_p(x), x.ld, x.P, x.C, _p(gamma), _p(beta), eps, momentum,
                                           _p(moving_mean), _p(moving_var), _p(affine), _p(saved), ws.ptr, ws.nbytes,
                                           _stream()), "bn_stats")
 
 
 def bn_apply(x: Act, affine, y: Act, relu=True):
-    check(_lib.lib().unetrir_bn_apply_f32(_p(x), x.ld, x.P, x.C, _p(affine), int(relu), _p(y), y.ld, _stream()),
+    check(_fn("bn_apply", x.sfx)(_p(x), x.ld, x.P, x.C, _p(affine), int(relu), _p(y), y.ld, _stream()),
           "bn_apply")
 
 
 def bn_bwd(da: Act, x: Act, gamma, affine, saved, dx: Act, dgamma, dbeta, ws: Workspace, relu=True):
     ws.reserve(bn_ws_bytes(x.P, x.C))
-    check(_lib.lib().unetrir_bn_bwd_f32(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(gamma), _p(affine), _p(saved),
-                                        int(relu), _p(dx), dx.ld, _p(dgamma), _p(dbeta), ws.ptr, ws.nbytes,
-                                        _stream()), "bn_bwd")
+    if x.sfx == "f32":
+        check(_lib.lib().unetrir_bn_bwd_f32(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(gamma), _p(affine), _p(saved),
+                                            int(relu), _p(dx), dx.ld, _p(dgamma), _p(dbeta), ws.ptr, ws.nbytes,
+                                            _stream()), "bn_bwd")
+    else:
+        check(_lib.lib().unetrir_bn_bwd_bf16(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(affine), _p(saved), int(relu),
+                                             _p(dx), dx.ld, _p(dgamma), _p(dbeta), ws.ptr, ws.nbytes, _stream()),
+              "bn_bwd")
 
 
 def colsum(x: Act, out, ws: Workspace):
     """Bias gradient: out[c] = sum over pixels."""
     ws.reserve(bn_ws_bytes(x.P, x.C))
-    check(_lib.lib().unetrir_colsum_f32(_p(x), x.ld, x.P, x.C, _p(out), ws.ptr, ws.nbytes, _stream()), "colsum")
+    check(_fn("colsum", x.sfx)(_p(x), x.ld, x.P, x.C, _p(out), ws.ptr, ws.nbytes, _stream()), "colsum")
 
 
 def relu_fwd(x: Act, y: Act):
-    check(_lib.lib().unetrir_relu_fwd_f32(_p(x), x.ld, x.P, x.C, _p(y), y.ld, _stream()), "relu_fwd")
+    if x.sfx == "f32":
+        check(_lib.lib().unetrir_relu_fwd_f32(_p(x), x.ld, x.P, x.C, _p(y), y.ld, _stream()), "relu_fwd")
+    else:
+        check(_lib.lib().unetrir_bn_apply_bf16(_p(x), x.ld, x.P, x.C, None, 1, _p(y), y.ld, _stream()), "relu_fwd")
 
 
 def relu_bwd(da: Act, x: Act, dx: Act):
-    check(_lib.lib().unetrir_relu_bwd_f32(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(dx), dx.ld, _stream()),
+    check(_fn("relu_bwd", x.sfx)(_p(da), da.ld, _p(x), x.ld, x.P, x.C, _p(dx), dx.ld, _stream()),
           "relu_bwd")
 
 
@@ -178,7 +213,7 @@ def relu_bwd(da: Act, x: Act, dx: Act):
 
 def nchw_to_nhwc_pad(x, y: Act):
     B, C_, H, W = x.shape
-    check(_lib.lib().unetrir_nchw_to_nhwc_pad_f32(_p(x), B, C_, H, W, _p(y), y.ld, _stream()), "nchw_to_nhwc_pad")
+    check(_fn("nchw_to_nhwc_pad", y.sfx)(_p(x), B, C_, H, W, _p(y), y.ld, _stream()), "nchw_to_nhwc_pad")
 
 
 def head6x6_supported(C_):
@@ -187,13 +222,13 @@ def head6x6_supported(C_):
 
 def head6x6_fwd(x: Act, w, bias, y: Act):
     """Conv2D(2, (6,6), padding='same') (dl_models/u_net.py:248), direct kernel."""
-    check(_lib.lib().unetrir_head6x6_fwd_f32(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(w), _p(bias), _p(y), y.ld, _stream()),
+    check(_fn("head6x6_fwd", x.sfx)(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(w), _p(bias), _p(y), y.ld, _stream()),
           "head6x6_fwd")
 
 
 def head6x6_wgrad(x: Act, dy: Act, dw, ws: Workspace):
     ws.reserve(_lib.lib().unetrir_head6x6_wgrad_ws_bytes(x.C))
-    check(_lib.lib().unetrir_head6x6_wgrad_f32(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(dy), dy.ld, _p(dw), ws.ptr, ws.nbytes,
+    check(_fn("head6x6_wgrad", x.sfx)(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(dy), dy.ld, _p(dw), ws.ptr, ws.nbytes,
                                                _stream()), "head6x6_wgrad")
 
 
@@ -201,9 +236,8 @@ def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_
     """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits."""
     B, _, H, W = target.shape
     ws.reserve(_lib.lib().unetrir_loss_ws_bytes(B * H * W))
-    check(_lib.lib().unetrir_sigmoid_loss_f32(_p(logits), logits.ld, _p(target), B, H, W, alpha, inv_norm, _p(pred),
-                                              _p(dlogits), _p(loss_out), ws.ptr, ws.nbytes, _stream()),
-          "sigmoid_loss")
+    check(_fn("sigmoid_loss", dlogits.sfx)(_p(logits), logits.ld, _p(target), B, H, W, alpha, inv_norm, _p(pred),
+                                           _p(dlogits), _p(loss_out), ws.ptr, ws.nbytes, _stream()), "sigmoid_loss")
 
 
 def sigmoid_nchw(logits: Act, pred):
@@ -213,7 +247,7 @@ def sigmoid_nchw(logits: Act, pred):
 
 def sigmoid_bwd(pred, dpred, dlogits: Act):
     B, _, H, W = pred.shape
-    check(_lib.lib().unetrir_sigmoid_bwd_f32(_p(pred), _p(dpred), B, H, W, _p(dlogits), _stream()), "sigmoid_bwd")
+    check(_fn("sigmoid_bwd", dlogits.sfx)(_p(pred), _p(dpred), B, H, W, _p(dlogits), _stream()), "sigmoid_bwd")
 
 
 # ---- information vector ----------------------------------------------------------------------
