@@ -21,7 +21,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+# dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md: fp32 v_mfma_f32_32x32x2_f32 = 256 CU x 4 SIMD x 64 FLOP/clk
+# x 2.4 GHz; bf16 ~2.5 PFLOP/s dense (the 5 PF headline includes 2:1 sparsity)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 
 
 def synthetic_batch(B, H, W, device, seed):
@@ -76,6 +78,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event bracketing of conv kernels")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of activations/gradients (accumulation, statistics, master weights: fp32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,7 +99,8 @@ def main():
 
     import unet_rir_amd as U
     H = W = args.size
-    eng = U.UNetEngine(H, W, args.batch, F0=args.f0, k=3, depth=args.depth, device=device, n_replicas=world)
+    eng = U.UNetEngine(H, W, args.batch, F0=args.f0, k=3, depth=args.depth, device=device, n_replicas=world,
+                       dtype=args.dtype)
     gen = torch.Generator()
     gen.manual_seed(0)                                   # identical initial variables on every replica
     eng.reset_parameters(gen)
@@ -142,8 +147,8 @@ def main():
         "unit": "spectrograms/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"UNet 4 down/4 up, number_filters_0={args.f0}, kernels=3, per-GPU batch {args.batch} of "
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"UNet {args.depth} down/{args.depth} up, number_filters_0={args.f0}, kernels=3, per-GPU batch {args.batch} of "
                                f"[2,{H},{W}] + [2,16] (BASELINE.json configs[1] per GPU; global batch {global_batch}), "
                                "full train step: fwd + loss + bwd + grad all-reduce + Adam",
                    "global_batch": global_batch, "parallelism": f"dp{world}", "params": eng.n_params()},
@@ -154,11 +159,13 @@ def main():
         conv_ms = sum(fms[0:3])
         conv_fl = sum(ffl[0:3])
         ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
         out["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": "igemm_fwd_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv: fwd, dgrad, wgrad; layers with "
-                      "Cin,Cout >= 8)",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": None,
+            "kernel": ("igemm_fwd_kernel / wgrad3x3_kernel (fp32 MFMA 32x32x2 implicit-GEMM conv: fwd, dgrad, wgrad)" if args.dtype == "f32"
+                       else "igemm_fwd_bf16_kernel / wgrad3x3_bf16_kernel (bf16 MFMA 32x32x16 implicit-GEMM conv: fwd, dgrad, wgrad)")
+                      + "; layers with Cin,Cout >= 8",
             "launches_per_step": sum(counts[0:3]) / args.steps,
             "avg_launch_ms": conv_ms / max(sum(counts[0:3]), 1),
             "algorithmic_gflop_per_step": conv_fl / args.steps / 1e9,
@@ -169,7 +176,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.f0, H, W)
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -141,7 +141,7 @@ int unetrir_sigmoid_bwd_f32(const float* pred, const float* dpred, int B, int H,
                             float* dlogits, unetrir_stream_t stream);
 
 /* ---- output head Conv2D(2, (6,6), padding='same') (dl_models/u_net.py:248), direct (non-MFMA) kernels: with 2
- *      output channels an implicit GEMM would waste 15/16 of every MFMA tile.  C % 16 == 0.
+ *      output channels an implicit GEMM would waste 15/16 of every MFMA tile.  C % 8 == 0.
  *      fwd: w is [>=2][6][6][C] (rows 0,1 used); y is [B*H*W][ldy], ldy >= 2; with ldy >= 4 channels 2,3 are zeroed.
  *      wgrad: dw[0..1][6][6][C] = sum_pixels dy[p][0..1] * x[p+off][c]; dy is [B*H*W][lddy>=2]; further rows of a
  *      padded kernel gradient are left untouched.  ws >= unetrir_head6x6_wgrad_ws_bytes(C). */

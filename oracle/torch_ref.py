@@ -191,35 +191,81 @@ def bn_relu(x, gamma, beta, state, name, training, relu=True):
     return F.relu(y) if relu else y
 
 
-def conv_block_1(x, P, name, cfg, state, training, inter):
+class _QuantSTE(torch.autograd.Function):
+    """Models a tensor STORED in bfloat16: the value is rounded to bf16 on the way forward and its gradient is
+    rounded to bf16 on the way back (the product keeps both the activation and its gradient in bf16 buffers)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _QuantFwd(torch.autograd.Function):
+    """bf16 work copy of an fp32 master weight: rounded forward, gradient passed through (weight gradients are fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _QuantBwd(torch.autograd.Function):
+    """fp32 tensor whose gradient is stored in bf16 (the logits)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _ident(x):
+    return x
+
+
+def conv_block_1(x, P, name, cfg, state, training, inter, q=_ident, qw=_ident):
     """UNet.convolutional_block_1 (dl_models/u_net.py:363-371)."""
-    y = conv2d_same(x, P[name + ".kernel"], P[name + ".bias"], 1)
+    y = q(conv2d_same(x, qw(P[name + ".kernel"]), P[name + ".bias"], 1))
     if inter is not None:
         inter[name + ".conv"] = y
     if cfg.batchnorm:
         y = bn_relu(y, P[name + ".gamma"], P[name + ".beta"], state, name, training)
     else:
         y = F.relu(y)
+    y = q(y)
     if inter is not None:
         inter[name + ".out"] = y
     return y
 
 
 def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
-            dropout_mask: Optional[torch.Tensor] = None, bn_state=None, inter=None):
+            dropout_mask: Optional[torch.Tensor] = None, bn_state=None, inter=None, storage=None):
     """UNet._build graph (dl_models/u_net.py:201-251), mode 0.
     spec [B,2,H,W] NCHW, emb int [B,2,16] -> [B,2,H,W] in (0,1).
-    dropout_mask: [B, h5*w5*16] keep mask already scaled by 1/(1-p) (None = no dropout)."""
-    x = spec
+    dropout_mask: [B, h5*w5*16] keep mask already scaled by 1/(1-p) (None = no dropout).
+    storage="bf16" restates the product's bf16 mode: every trunk activation and its gradient are rounded to bf16
+    where the product stores them, trunk kernels are used as bf16 work copies; arithmetic stays in the tensor dtype."""
+    q = _QuantSTE.apply if storage == "bf16" else _ident
+    qw = _QuantFwd.apply if storage == "bf16" else _ident
+    x = q(spec)
     skips = []
     n_levels = cfg.depth + 1
     for l in range(1, n_levels + 1):
         stride = cfg.s0 if l == 1 else cfg.s
         # encoding_block (dl_models/u_net.py:265-289): strided conv (bias, no BN/act) + block
-        x = conv2d_same(x, P[f"enc{l}.down.kernel"], P[f"enc{l}.down.bias"], stride)
+        x = q(conv2d_same(x, qw(P[f"enc{l}.down.kernel"]), P[f"enc{l}.down.bias"], stride))
         if inter is not None:
             inter[f"enc{l}.down"] = x
-        x = conv_block_1(x, P, f"enc{l}.cb1", cfg, bn_state, training, inter)
+        x = conv_block_1(x, P, f"enc{l}.cb1", cfg, bn_state, training, inter, q, qw)
         skips.append(x)
     # vector_block (dl_models/u_net.py:253-263)
     B = spec.shape[0]
@@ -233,19 +279,21 @@ def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
         inter["vec.dense"] = v
     v = v.view(B, h5, w5, VEC_CH).permute(0, 3, 1, 2)    # Reshape((h5,w5,16)) is NHWC
     v = conv2d_same(v, P["vec.conv.kernel"], P["vec.conv.bias"], 1)
-    x = x + v                                            # Add() (dl_models/u_net.py:229)
+    x = q(x + v)                                         # Add() (dl_models/u_net.py:229); the vector branch stays fp32
     if inter is not None:
         inter["bottleneck"] = x
     # decoding_block (dl_models/u_net.py:291-321)
     for l in range(cfg.depth, 0, -1):
-        x = conv2d_transpose_same(x, P[f"dec{l}.up.kernel"], P[f"dec{l}.up.bias"], cfg.s)
+        x = q(conv2d_transpose_same(x, qw(P[f"dec{l}.up.kernel"]), P[f"dec{l}.up.bias"], cfg.s))
         if inter is not None:
             inter[f"dec{l}.up"] = x
-        x = torch.cat([skips[l - 1], x], dim=1)          # concatenate([skip, x]) (:308)
-        x = conv_block_1(x, P, f"dec{l}.cb1a", cfg, bn_state, training, inter)
-        x = conv_block_1(x, P, f"dec{l}.cb1b", cfg, bn_state, training, inter)
+        x = q(torch.cat([skips[l - 1], x], dim=1))       # concatenate([skip, x]) (:308)
+        x = conv_block_1(x, P, f"dec{l}.cb1a", cfg, bn_state, training, inter, q, qw)
+        x = conv_block_1(x, P, f"dec{l}.cb1b", cfg, bn_state, training, inter, q, qw)
     # UpSampling2D((1,1)) is the identity; Conv2D(2,(6,6),'same') + sigmoid (:247-249)
-    x = conv2d_same(x, P["head.kernel"], P["head.bias"], 1)
+    x = conv2d_same(x, P["head.kernel"], P["head.bias"], 1)      # logits stay fp32 in every mode
+    if storage == "bf16":
+        x = _QuantBwd.apply(x)                                   # ... but dL/dlogits is stored in bf16
     if inter is not None:
         inter["head.logits"] = x
     return torch.sigmoid(x)
@@ -278,7 +326,7 @@ def to_torch(params: Dict[str, np.ndarray], dtype=torch.float32, requires_grad=F
 
 
 def loss_and_grads(params, spec_in, emb, spec_out, cfg: Config, alpha=0.9, global_batch=None,
-                   n_replicas=1, dropout_mask=None, dtype=torch.float32, inter=None, bn_state=None):
+                   n_replicas=1, dropout_mask=None, dtype=torch.float32, inter=None, bn_state=None, storage=None):
     """One forward + backward of train_step (main_training.py:253-268) up to the gradients."""
     P = to_torch(params, dtype, True)
     spec_in = torch.as_tensor(np.asarray(spec_in)).to(dtype)
@@ -286,7 +334,7 @@ def loss_and_grads(params, spec_in, emb, spec_out, cfg: Config, alpha=0.9, globa
     emb = torch.as_tensor(np.asarray(emb))
     if dropout_mask is not None:
         dropout_mask = torch.as_tensor(np.asarray(dropout_mask)).to(dtype)
-    pred = forward(P, spec_in, emb, cfg, True, dropout_mask, bn_state, inter)
+    pred = forward(P, spec_in, emb, cfg, True, dropout_mask, bn_state, inter, storage)
     dl = data_loss(spec_out, pred, alpha, global_batch)
     loss = dl + reg_loss(P, cfg, n_replicas)
     loss.backward()

@@ -38,7 +38,7 @@ def test_argument_validation_without_gpu():
     assert L.unetrir_conv2d_fwd_f32(C.byref(g), 16, 8, 16, None, None, 0, 16, 8, None) == 10001
     assert L.unetrir_bn_ws_bytes(1024, 64) > 0
     assert L.unetrir_conv2d_wgrad_ws_bytes(C.byref(ConvGeom(32, 256, 256, 64, 64, 3, 1))) > 0
-    assert L.unetrir_head6x6_supported(64) == 1 and L.unetrir_head6x6_supported(20) == 0
+    assert L.unetrir_head6x6_supported(64) == 1 and L.unetrir_head6x6_supported(8) == 1 and L.unetrir_head6x6_supported(20) == 0
 
 
 def test_product_has_no_cpu_fallback_and_does_not_import_oracle():

@@ -163,3 +163,91 @@ def test_depth5_graph(U):
     cfg, Pn, eng, tr, ref, _ = run_case(U, 64, 64, 4, 2, depth=5)
     assert eng.hw[-1] == (2, 2) and eng.ch[-1] == 4 * 32
     check_against_oracle(eng, ref)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bf16 storage mode (BASELINE.json configs[1] names bf16).  The oracle restates it exactly: every trunk activation and its
+# gradient are rounded to bf16 where the product stores them (oracle/torch_ref.py storage="bf16"), arithmetic in fp64.
+# ------------------------------------------------------------------------------------------------------------------
+def _bf16_case(U, H, W, F0, B):
+    cfg = R.Config(H, W, F0, 3)
+    Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
+    eng = U.UNetEngine(H, W, B, F0=F0, device=DEV, dtype="bf16")
+    eng.load_keras_params(Pn)
+    t = lambda a: torch.tensor(a).to(DEV)
+    eng.forward(t(spec_in), t(emb), target=t(spec_out), global_batch=B)
+    eng.backward()
+    eng.reg_loss()
+    torch.cuda.synchronize()
+    return cfg, Pn, (spec_in, emb, spec_out), eng
+
+
+def test_bf16_forward_matches_bf16_storage_oracle(U):
+    """Forward pass of the bf16 mode against the oracle with the same storage rounding: the first two levels are
+    bit-identical; deeper, single 1-ulp rounding decisions (fp32 vs fp64 accumulation landing on either side of a bf16
+    rounding boundary) propagate, so everything stays within a few bf16 ulps: 2% of each tensor's scale."""
+    cfg, Pn, (spec_in, emb, spec_out), eng = _bf16_case(U, 32, 32, 8, 2)
+    P = R.to_torch(Pn, torch.float64)
+    inter = {}
+    pred = R.forward(P, torch.tensor(spec_in).double(), torch.tensor(emb), cfg, True, None, None, inter, "bf16")
+    loss = float(R.data_loss(torch.tensor(spec_out).double(), pred, 0.9, 2) + R.reg_loss(P, cfg, 1))
+
+    def err(name, act):
+        e = inter[name]
+        a = act.dense().permute(0, 3, 1, 2).double().cpu()
+        return float((a - e).abs().max()), float(e.abs().max())
+    for name, act in [("enc1.down", eng.down[1]), ("enc1.cb1.conv", eng.y[1]), ("enc1.cb1.out", eng.a[1]),
+                      ("enc2.down", eng.down[2]), ("enc2.cb1.conv", eng.y[2])]:
+        assert err(name, act)[0] == 0.0, name
+    for l in range(1, 6):
+        for name, act in [(f"enc{l}.down", eng.down[l]), (f"enc{l}.cb1.out", eng.a[l])]:
+            e, s = err(name, act)
+            assert e <= 2e-2 * s, (name, e, s)
+    for l in range(1, 5):
+        for name, act in [(f"dec{l}.up", eng.cat[l].slice(eng.ch[l - 1], eng.ch[l - 1])), (f"dec{l}.cb1b.out", eng.ab[l])]:
+            e, s = err(name, act)
+            assert e <= 2e-2 * s, (name, e, s)
+    assert float((eng.pred.double().cpu() - pred).abs().max()) <= 2e-2
+    got = float(eng.loss_out[0]) + float(eng.reg_out[0])
+    assert abs(got - loss) <= 1e-3 * abs(loss), (got, loss)
+
+
+def test_bf16_gradients_as_accurate_as_the_storage_model_allows(U):
+    """bf16 storage makes the gradient of this network noisy by itself (rounding noise is amplified through BatchNorm at
+    the small deep levels).  The HIP bf16 path must be as close to the exact (fp64, unrounded) gradient as the oracle's
+    own bf16-storage model is: per tensor, relative L2 error <= 2x the oracle's + 2%."""
+    cfg, Pn, (spec_in, emb, spec_out), eng = _bf16_case(U, 64, 64, 8, 4)
+    _, _, _, g_true = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, dtype=torch.float64)
+    _, _, _, g_q = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, dtype=torch.float64, storage="bf16")
+    kg = eng.export_keras_grads()
+    checked = 0
+    for n, gt in g_true.items():
+        if n.endswith(("cb1.bias", "cb1a.bias", "cb1b.bias")):
+            continue                               # analytically zero gradients
+        nt = float(gt.norm()) + 1e-30
+        e_hip = float((kg[n].double() - gt).norm()) / nt
+        e_orc = float((g_q[n] - gt).norm()) / nt
+        assert e_hip <= 2.0 * e_orc + 0.02, (n, e_hip, e_orc)
+        checked += 1
+    assert checked > 50
+    # the layers next to the loss see almost no accumulated rounding: they are tight in absolute terms too
+    for n, tol in [("head.kernel", 1e-2), ("head.bias", 5e-3), ("dec1.cb1b.gamma", 2e-2)]:
+        gt = g_true[n]
+        assert float((kg[n].double() - gt).norm()) <= tol * float(gt.norm()), n
+
+
+def test_bf16_train_step_reduces_loss_and_is_deterministic(U):
+    cfg, Pn, (spec_in, emb, spec_out), eng = _bf16_case(U, 32, 32, 8, 2)
+    t = lambda a: torch.tensor(a).to(DEV)
+    g1 = eng.grad.clone()
+    eng.forward(t(spec_in), t(emb), target=t(spec_out), global_batch=2)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, eng.grad)
+    tr = U.Trainer(eng, lr=1e-3, dropout=False)
+    l0 = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
+    for _ in range(20):
+        l1 = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
+    assert np.isfinite(l1) and l1 < l0
+    assert float(eng.p["enc1.down.kernel"][..., 2:].abs().max()) == 0.0 and float(eng.p["head.kernel"][2:].abs().max()) == 0.0

@@ -152,26 +152,29 @@ namespace {
 
 template <typename T>
 int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s) {
-    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 16) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
         return UNETRIR_EINVAL;
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
     if (C % 32 == 0) hipLaunchKernelGGL((head_fwd_kernel<32, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
-    else hipLaunchKernelGGL((head_fwd_kernel<16, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
+    else if (C % 16 == 0) hipLaunchKernelGGL((head_fwd_kernel<16, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
+    else hipLaunchKernelGGL((head_fwd_kernel<8, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
     return (int)hipGetLastError();
 }
 
 template <typename T>
 int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy, int lddy, float* dw, void* ws, size_t ws_bytes,
                     hipStream_t s) {
-    if (!x || !dy || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 16) || ldx < C || (ldx & 3) || lddy < 2 || (lddy & 1) ||
+    if (!x || !dy || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || lddy < 2 || (lddy & 1) ||
         ws_bytes < (size_t)HEAD_WGRAD_BLOCKS * 2 * HK * HK * C * sizeof(float))
         return UNETRIR_EINVAL;
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
     const int nblk = tiles < HEAD_WGRAD_BLOCKS ? (int)tiles : HEAD_WGRAD_BLOCKS;
     if (C % 32 == 0)
         hipLaunchKernelGGL((head_wgrad_kernel<32, T>), dim3(nblk, C / 32), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws, (int)tiles);
-    else
+    else if (C % 16 == 0)
         hipLaunchKernelGGL((head_wgrad_kernel<16, T>), dim3(nblk, C / 16), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws, (int)tiles);
+    else
+        hipLaunchKernelGGL((head_wgrad_kernel<8, T>), dim3(nblk, C / 8), dim3(256), 0, s, x, ldx, B, H, W, C, dy, lddy, (float*)ws, (int)tiles);
     const size_t nout = (size_t)2 * HK * HK * C;
     return launch_splitk_reduce((const float*)ws, nblk, nout, dw, 0.f, nullptr, s);
 }
@@ -180,7 +183,7 @@ int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy
 
 extern "C" {
 
-int unetrir_head6x6_supported(int C) { return (C % 16) == 0 ? 1 : 0; }
+int unetrir_head6x6_supported(int C) { return (C % 8) == 0 ? 1 : 0; }
 
 int unetrir_head6x6_fwd_f32(const float* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y,
                             int ldy, unetrir_stream_t stream) {

@@ -46,11 +46,19 @@ class UNetEngine:
     """One replica of the model for a fixed per-replica batch size B on one device."""
 
     def __init__(self, H, W, B, F0=32, k=3, depth=4, batchnorm=True, inf_vector_shape=(2, 16), s0=1, s=2,
-                 device="cuda:0", n_replicas=1):
+                 device="cuda:0", n_replicas=1, dtype="f32"):
         if s0 != 1 or s != 2:
             raise NotImplementedError("HIP path implements resize_factor_0=[1,1], res_factor=[2,2] (the reference defaults)")
-        if F0 % 4:
-            raise ValueError("number_filters_0 must be a multiple of 4")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        # storage type of activations and their gradients; parameters, statistics and weight gradients are always fp32
+        self.dtype = dtype
+        self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes
+        if F0 % self.PAD:
+            raise ValueError(f"number_filters_0 must be a multiple of {self.PAD} for dtype {dtype}")
+        if dtype == "bf16" and k != 3:
+            raise NotImplementedError("the bf16 path implements kernels=3 (weight gradient of 3x3 layers)")
         if k < 1 or k > 6:
             raise ValueError("kernels must be in 1..6")
         self.H, self.W, self.B, self.F0, self.k, self.depth = H, W, B, F0, k, depth
@@ -80,6 +88,8 @@ class UNetEngine:
         self.head_direct = ops.head6x6_supported(self.ch[0])
         if self.head_direct:
             self.ws.reserve(512 * 2 * 36 * self.ch[0] * 4)
+        elif self.dtype == "bf16":
+            raise ValueError("the bf16 path needs number_filters_0 % 8 == 0 (direct head kernels)")
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self):
@@ -95,8 +105,9 @@ class UNetEngine:
                 add(prefix + ".beta", (c,), "beta", (c,))
 
         # backward completion order: head, dec1..decD, vec, encL..enc1
-        add("head.kernel", (4, 6, 6, ch[0]), "conv_padout", (6, 6, ch[0], 2))
-        add("head.bias", (4,), "bias_pad", (2,))
+        PAD = self.PAD
+        add("head.kernel", (PAD, 6, 6, ch[0]), "conv_padout", (6, 6, ch[0], 2))
+        add("head.bias", (PAD,), "bias_pad", (2,))
         for l in range(1, self.depth + 1):
             c = ch[l - 1]
             add(f"dec{l}.cb1b.kernel", (c, 3, 3, c), "conv", (3, 3, c, c))
@@ -121,7 +132,7 @@ class UNetEngine:
             if l > 1:
                 add(f"enc{l}.down.kernel", (c, k, k, cin), "conv", (k, k, cin, c))
             else:
-                add(f"enc{l}.down.kernel", (c, k, k, 4), "conv_padin", (k, k, 2, c))
+                add(f"enc{l}.down.kernel", (c, k, k, PAD), "conv_padin", (k, k, 2, c))
             add(f"enc{l}.down.bias", (c,), "bias", (c,))
         off = 0
         for s_ in specs:
@@ -145,6 +156,19 @@ class UNetEngine:
                 toff += -(-s_.numel // ALIGN) * ALIGN
         self.theta_t = torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
         self.pt = {n: self.theta_t[o:o + self.specs[n].numel] for n, o in self.tspec.items()}
+        # bf16 mode: bf16 work copies of every trunk kernel in both orientations (the information-vector branch stays fp32)
+        self.ph, self.pth = {}, {}
+        if self.dtype == "bf16":
+            hoff, hspec = 0, []
+            for n, s_ in self.specs.items():
+                if s_.kind in ("conv", "convT", "conv_padin", "conv_padout") and not n.startswith("vec."):
+                    hspec.append((n, hoff)); hoff += -(-s_.numel // ALIGN) * ALIGN
+            self.theta_h = torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
+            self.theta_th = torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
+            for n, o in hspec:
+                k_ = self.specs[n].numel
+                self.ph[n] = self.theta_h[o:o + k_]
+                self.pth[n] = self.theta_th[o:o + k_]
         # BatchNorm moving statistics (non-trainable)
         self.bn_names = [n[:-len(".gamma")] for n in self.specs if n.endswith(".gamma")]
         self.moving = {}
@@ -236,8 +260,10 @@ class UNetEngine:
     # ------------------------------------------------------------------ buffers
     def _alloc(self):
         B, dev, ch, hw, D = self.B, self.device, self.ch, self.hw, self.depth
-        A = lambda h, w, c: ops.new_act(B, h, w, c, dev)
-        self.x4, self.down, self.y, self.a = A(self.H, self.W, 4), {}, {}, {}
+        A = lambda h, w, c: ops.new_act(B, h, w, c, dev, dtype=self.adt)      # trunk activations (fp32 or bf16)
+        F = lambda h, w, c: ops.new_act(B, h, w, c, dev)                      # always fp32
+        PAD = self.PAD
+        self.x4, self.down, self.y, self.a = A(self.H, self.W, PAD), {}, {}, {}
         self.cat, self.g_cat = {}, {}
         self.g_down, self.g_y = {}, {}
         for l in range(1, self.L + 1):
@@ -269,7 +295,9 @@ class UNetEngine:
             c = ch[l - 1]
             for d_ in (self.ya, self.aa, self.yb, self.ab, self.g_ya, self.g_aa, self.g_yb, self.g_ab):
                 d_[l] = A(h, w, c)
-        self.logits, self.g_logits = A(self.H, self.W, 4), A(self.H, self.W, 4)
+        self.logits, self.g_logits = F(self.H, self.W, 4), A(self.H, self.W, PAD)      # logits stay fp32 for sigmoid + loss
+        if self.dtype == "bf16":    # glue to the fp32 information-vector branch
+            self.v1x1, self.g_z32 = F(self.h5, self.w5, cL), F(self.h5, self.w5, cL)
         self.pred = torch.empty((B, 2, self.H, self.W), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self.reg_out = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -284,7 +312,7 @@ class UNetEngine:
             h, w = hw[l - 1]
             c = ch[l - 1]
             if l == 1:
-                self.geo["enc1.down"] = G(B, h, w, 4, c, k, 1)
+                self.geo["enc1.down"] = G(B, h, w, PAD, c, k, 1)
             else:
                 hi, wi = hw[l - 2]
                 self.geo[f"enc{l}.down"] = G(B, hi, wi, ch[l - 2], c, k, 2)
@@ -298,7 +326,7 @@ class UNetEngine:
             self.geo[f"dec{l}.up"] = G(B, hl, wl, ch[l], c, k, 2)
             self.geo[f"dec{l}.cb1a"] = G(B, h, w, 2 * c, c, k, 1)
             self.geo[f"dec{l}.cb1b"] = G(B, h, w, c, c, 3, 1)
-        self.geo["head"] = G(B, self.H, self.W, ch[0], 4, 6, 1)
+        self.geo["head"] = G(B, self.H, self.W, ch[0], PAD, 6, 1)
 
     def _reserve_workspace(self):
         need = 1 << 16
@@ -325,8 +353,23 @@ class UNetEngine:
                 T, C_ = 1, s_.shape[1]
             else:
                 T, C_ = s_.shape[1] * s_.shape[2], s_.shape[3]
+            if self.dtype == "bf16" and n in self.ph:
+                continue                                    # trunk kernels: bf16 copies below
             ops.transpose_weight(self.p[n], self.pt[n], N, T, C_)
+        for n in self.ph:
+            s_ = self.specs[n]
+            N, T, C_ = s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3]
+            ops.cast_weight_bf16(self.p[n], self.ph[n], N, T, C_, C_)
+            ops.transpose_cast_weight_bf16(self.p[n], self.pth[n], N, T, C_, N)
         self.t_dirty = False
+
+    def wf(self, name):
+        """Trunk kernel in its stored orientation, in the storage type of the trunk (fp32 master or bf16 work copy)."""
+        return self.ph[name] if self.dtype == "bf16" else self.p[name]
+
+    def wb(self, name):
+        """Trunk kernel with the channel roles swapped ([C][T][N]) in the storage type of the trunk."""
+        return self.pth[name] if self.dtype == "bf16" else self.pt[name]
 
     def _bn_relu_fwd(self, name, y: Act, out: Act):
         if self.batchnorm:
@@ -368,8 +411,8 @@ class UNetEngine:
         ops.nchw_to_nhwc_pad(spec, self.x4)
         prev = self.x4
         for l in range(1, self.L + 1):
-            ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, p[f"enc{l}.down.kernel"], p[f"enc{l}.down.bias"], self.down[l])
-            ops.conv2d_fwd(self.geo[f"enc{l}.cb1"], self.down[l], p[f"enc{l}.cb1.kernel"], p[f"enc{l}.cb1.bias"], self.y[l])
+            ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, self.wf(f"enc{l}.down.kernel"), p[f"enc{l}.down.bias"], self.down[l])
+            ops.conv2d_fwd(self.geo[f"enc{l}.cb1"], self.down[l], self.wf(f"enc{l}.cb1.kernel"), p[f"enc{l}.cb1.bias"], self.y[l])
             self._bn_relu_fwd(f"enc{l}.cb1", self.y[l], self.a[l])
             prev = self.a[l]
         # information vector branch (dl_models/u_net.py:253-263) + Add (:229)
@@ -381,15 +424,19 @@ class UNetEngine:
             vsp = self.vd_sp
         else:
             vsp = Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
-        ops.conv2d_fwd(self.geo["vec.conv"], vsp, p["vec.conv.kernel"], p["vec.conv.bias"], self.z, addend=self.a[self.L])
+        if self.dtype == "f32":
+            ops.conv2d_fwd(self.geo["vec.conv"], vsp, p["vec.conv.kernel"], p["vec.conv.bias"], self.z, addend=self.a[self.L])
+        else:   # the branch is fp32; its 1x1 conv output joins the bf16 trunk through the Add()
+            ops.conv2d_fwd(self.geo["vec.conv"], vsp, p["vec.conv.kernel"], p["vec.conv.bias"], self.v1x1)
+            ops.add_f32_to_bf16(self.a[self.L], self.v1x1, self.z)
         cur = self.z
         for l in range(D, 0, -1):
             c = self.ch[l - 1]
-            ops.conv2d_transpose_fwd(self.geo[f"dec{l}.up"], cur, self.pt[f"dec{l}.up.kernel"], p[f"dec{l}.up.bias"],
+            ops.conv2d_transpose_fwd(self.geo[f"dec{l}.up"], cur, self.wb(f"dec{l}.up.kernel"), p[f"dec{l}.up.bias"],
                                      self.cat[l].slice(c, c))
-            ops.conv2d_fwd(self.geo[f"dec{l}.cb1a"], self.cat[l], p[f"dec{l}.cb1a.kernel"], p[f"dec{l}.cb1a.bias"], self.ya[l])
+            ops.conv2d_fwd(self.geo[f"dec{l}.cb1a"], self.cat[l], self.wf(f"dec{l}.cb1a.kernel"), p[f"dec{l}.cb1a.bias"], self.ya[l])
             self._bn_relu_fwd(f"dec{l}.cb1a", self.ya[l], self.aa[l])
-            ops.conv2d_fwd(self.geo[f"dec{l}.cb1b"], self.aa[l], p[f"dec{l}.cb1b.kernel"], p[f"dec{l}.cb1b.bias"], self.yb[l])
+            ops.conv2d_fwd(self.geo[f"dec{l}.cb1b"], self.aa[l], self.wf(f"dec{l}.cb1b.kernel"), p[f"dec{l}.cb1b.bias"], self.yb[l])
             self._bn_relu_fwd(f"dec{l}.cb1b", self.yb[l], self.ab[l])
             cur = self.ab[l]
         if self.head_direct:
@@ -438,19 +485,19 @@ class UNetEngine:
         ready("head.bias")
         top = self.ab[1] if D >= 1 else self.a[1]
         g_cur = self.g_ab[1] if D >= 1 else self.g_z
-        ops.conv2d_dgrad(self.geo["head"], gl, pt["head.kernel"], g_cur)
+        ops.conv2d_dgrad(self.geo["head"], gl, self.wb("head.kernel"), g_cur)
         for l in range(1, D + 1):
             c = self.ch[l - 1]
             # cb1b
             self._bn_relu_bwd(f"dec{l}.cb1b", self.g_ab[l], self.yb[l], self.g_yb[l])
             ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws)
             ops.colsum(self.g_yb[l], g[f"dec{l}.cb1b.bias"], ws)
-            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1b"], self.g_yb[l], pt[f"dec{l}.cb1b.kernel"], self.g_aa[l])
+            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1b"], self.g_yb[l], self.wb(f"dec{l}.cb1b.kernel"), self.g_aa[l])
             # cb1a
             self._bn_relu_bwd(f"dec{l}.cb1a", self.g_aa[l], self.ya[l], self.g_ya[l])
             ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws)
             ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws)
-            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1a"], self.g_ya[l], pt[f"dec{l}.cb1a.kernel"], self.g_cat[l])
+            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1a"], self.g_ya[l], self.wb(f"dec{l}.cb1a.kernel"), self.g_cat[l])
             # Conv2DTranspose
             g_up = self.g_cat[l].slice(c, c)
             x_in = self.ab[l + 1] if l < D else self.z
@@ -459,9 +506,12 @@ class UNetEngine:
                                        w=p[f"dec{l}.up.kernel"])
             ops.colsum(g_up, g[f"dec{l}.up.bias"], ws)
             ready(f"dec{l}.up.bias")
-            ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, p[f"dec{l}.up.kernel"], g_in)
+            ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, self.wf(f"dec{l}.up.kernel"), g_in)
         # bottleneck: z = a_L + conv1x1(dropout(dense(embedding)))
         gz = self.g_z
+        if self.dtype == "bf16":      # the information-vector branch is fp32: give it an fp32 copy of dL/dz
+            ops.cast_bf16_to_f32(self.g_z, self.g_z32)
+            gz = self.g_z32
         B = self.B
         has_do = self.dropout_mask is not None
         vsp = self.vd_sp if has_do else Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
@@ -479,12 +529,12 @@ class UNetEngine:
         ops.embedding_bwd(self.emb_idx, self.g_emb_out, g["vec.embedding"])
         ready("vec.embedding")
         # encoder, deepest level first; the gradient of a_l is (skip half of g_cat_l) + dgrad of the next strided conv
-        g_a = gz
+        g_a = self.g_z
         for l in range(self.L, 0, -1):
             self._bn_relu_bwd(f"enc{l}.cb1", g_a, self.y[l], self.g_y[l])
             ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws)
             ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws)
-            ops.conv2d_dgrad(self.geo[f"enc{l}.cb1"], self.g_y[l], pt[f"enc{l}.cb1.kernel"], self.g_down[l])
+            ops.conv2d_dgrad(self.geo[f"enc{l}.cb1"], self.g_y[l], self.wb(f"enc{l}.cb1.kernel"), self.g_down[l])
             x_in = self.a[l - 1] if l > 1 else self.x4
             ops.conv2d_wgrad(self.geo[f"enc{l}.down"], x_in, self.g_down[l], g[f"enc{l}.down.kernel"], ws, reg=reg,
                              w=p[f"enc{l}.down.kernel"])
@@ -492,7 +542,7 @@ class UNetEngine:
             ready(f"enc{l}.down.bias")
             if l > 1:
                 skip = self.g_cat[l - 1].slice(0, self.ch[l - 2])
-                ops.conv2d_dgrad(self.geo[f"enc{l}.down"], self.g_down[l], pt[f"enc{l}.down.kernel"], skip, addend=skip)
+                ops.conv2d_dgrad(self.geo[f"enc{l}.down"], self.g_down[l], self.wb(f"enc{l}.down.kernel"), skip, addend=skip)
                 g_a = skip
 
     # ------------------------------------------------------------------ optimizer
