@@ -41,7 +41,7 @@ def synthetic_batch(B, H, W, device, seed):
     return spec_in.contiguous(), emb, spec_out.contiguous()
 
 
-def cpu_baseline(F0, H, W, budget_s=25.0):
+def cpu_baseline(F0, H, W, budget_s=45.0):
     """The CPU restatement of the same train step (oracle/torch_ref.py, stock torch CPU ops) on this box's host cores,
     on a bounded sample: the same model at batch 4, a few steps."""
     from oracle import torch_ref as R
@@ -66,41 +66,11 @@ def cpu_baseline(F0, H, W, budget_s=25.0):
                       f"oracle/torch_ref.py on torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--f0", type=int, default=64)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--depth", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event bracketing of conv kernels")
-    ap.add_argument("--bucket-mb", type=int, default=32)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="storage type of activations/gradients (accumulation, statistics, master weights: fp32)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("UNETRIR_FORCE_DP") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    import unet_rir_amd as U
+def run_mode(U, args, dtype, world, rank, device, steps, warmup):
+    """Build the engine in one storage mode, run `warmup` untimed and `steps` timed train steps; returns a result dict
+    (rank 0) or None.  Timing: barrier + synchronize on both sides, MAX over ranks."""
     H = W = args.size
-    eng = U.UNetEngine(H, W, args.batch, F0=args.f0, k=3, depth=args.depth, device=device, n_replicas=world,
-                       dtype=args.dtype)
+    eng = U.UNetEngine(H, W, args.batch, F0=args.f0, k=3, depth=args.depth, device=device, n_replicas=world, dtype=dtype)
     gen = torch.Generator()
     gen.manual_seed(0)                                   # identical initial variables on every replica
     eng.reset_parameters(gen)
@@ -114,14 +84,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         tr.step(spec_in, emb, spec_out)
     sync()
     prof = (not args.no_prof) and rank == 0
     if prof:
         U.ops.prof_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         tr.step(spec_in, emb, spec_out)
     sync()
     dt = time.perf_counter() - t0
@@ -134,45 +104,101 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+    n_params = eng.n_params()
+    del tr, eng
+    torch.cuda.empty_cache()
     if rank != 0:
-        if world > 1:
+        return None
+    global_batch = args.batch * world
+    res = {"value": global_batch * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "dtype": dtype,
+           "loss": loss, "params": n_params}
+    if fam is not None:
+        counts, fms, ffl = fam
+        conv_ms, conv_fl, nl = sum(fms[0:3]), sum(ffl[0:3]), sum(counts[0:3])
+        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        peak = MFMA_PEAK_TFLOPS[dtype]
+        res["roofline"] = {
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "kernel": ("igemm_fwd_kernel / wgrad3x3_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv: fwd, dgrad, wgrad)"
+                       if dtype == "f32" else
+                       "igemm_fwd_bf16_kernel / wgrad3x3_bf16_kernel (bf16 v_mfma_f32_32x32x16_bf16 implicit-GEMM conv: fwd, dgrad, "
+                       "wgrad)") + "; layers with Cin,Cout > 8",
+            "calls_per_step": nl / steps, "avg_call_ms": conv_ms / max(nl, 1),
+            "algorithmic_gflop_per_step": conv_fl / steps / 1e9, "conv_ms_per_step": conv_ms / steps,
+            "by_family": {name: {"calls": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
+                          for i, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad"), (5, "stem_head_dgrad"))},
+        }
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--f0", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event bracketing of conv kernels")
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--dtype", choices=["bf16", "f32", "both"], default="both",
+                    help="storage type of activations/gradients (accumulation, statistics, master weights are always fp32). "
+                         "'both' (default): bf16 is the headline line (BASELINE.json configs[1] names bf16) and the fp32 "
+                         "parity mode is measured as well and reported under 'fp32_mode'")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1 or os.environ.get("UNETRIR_FORCE_DP") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import unet_rir_amd as U
+    H = W = args.size
+    head_dtype = "bf16" if args.dtype in ("bf16", "both") else "f32"
+    main_res = run_mode(U, args, head_dtype, world, rank, device, args.steps, args.warmup)
+    f32_res = None
+    if args.dtype == "both":
+        f32_res = run_mode(U, args, "f32", world, rank, device, min(args.steps, 5), min(args.warmup, 2))
+    if rank != 0:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
     global_batch = args.batch * world
-    ms = dt * 1e3 / args.steps
     out = {
         "metric": "RIR spectrograms/sec (train step) on [B,2,256,256] U-Net",
-        "value": global_batch * args.steps / dt,
+        "value": main_res["value"],
         "unit": "spectrograms/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"UNet {args.depth} down/{args.depth} up, number_filters_0={args.f0}, kernels=3, per-GPU batch {args.batch} of "
-                               f"[2,{H},{W}] + [2,16] (BASELINE.json configs[1] per GPU; global batch {global_batch}), "
-                               "full train step: fwd + loss + bwd + grad all-reduce + Adam",
-                   "global_batch": global_batch, "parallelism": f"dp{world}", "params": eng.n_params()},
-        "loss": loss,
+        "dtype": head_dtype, "data": "synthetic",
+        "config": {"workload": f"UNet {args.depth} down/{args.depth} up, number_filters_0={args.f0}, kernels=3, per-GPU batch "
+                               f"{args.batch} of [2,{H},{W}] + [2,16] (BASELINE.json configs[1] per GPU; global batch "
+                               f"{global_batch}), full train step: fwd + loss + bwd + grad all-reduce + Adam; "
+                               + ("bf16 activations/gradients, fp32 accumulate/statistics/master weights" if head_dtype == "bf16"
+                                  else "fp32 throughout"),
+                   "global_batch": global_batch, "parallelism": f"dp{world}", "params": main_res["params"]},
+        "loss": main_res["loss"],
     }
-    if fam is not None:
-        counts, fms, ffl = fam
-        conv_ms = sum(fms[0:3])
-        conv_fl = sum(ffl[0:3])
-        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
-        out["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": None,
-            "kernel": ("igemm_fwd_kernel / wgrad3x3_kernel (fp32 MFMA 32x32x2 implicit-GEMM conv: fwd, dgrad, wgrad)" if args.dtype == "f32"
-                       else "igemm_fwd_bf16_kernel / wgrad3x3_bf16_kernel (bf16 MFMA 32x32x16 implicit-GEMM conv: fwd, dgrad, wgrad)")
-                      + "; layers with Cin,Cout >= 8",
-            "launches_per_step": sum(counts[0:3]) / args.steps,
-            "avg_launch_ms": conv_ms / max(sum(counts[0:3]), 1),
-            "algorithmic_gflop_per_step": conv_fl / args.steps / 1e9,
-            "conv_ms_per_step": conv_ms / args.steps,
-            "by_family": {name: {"launches": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
-                          for i, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad"), (5, "stem_head"))},
-        }
+    if "roofline" in main_res:
+        out["roofline"] = main_res["roofline"]
+    if f32_res is not None:
+        out["fp32_mode"] = {k: f32_res[k] for k in ("value", "ms_per_step", "steps", "warmup", "loss") if k in f32_res}
+        out["fp32_mode"]["unit"] = "spectrograms/s"
+        out["fp32_mode"]["note"] = "same workload with fp32 storage: the mode the fp32-tolerance parity tests run in"
+        if "roofline" in f32_res:
+            out["fp32_mode"]["roofline"] = f32_res["roofline"]
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.f0, H, W)
     print(json.dumps(out))

@@ -54,7 +54,7 @@ inline double conv_flops(const unetrir_conv_geom* g) {
     return 2.0 * g->B * sy.out * sx.out * (double)g->Cout * g->Cin * g->k * g->k;
 }
 inline int conv_family(const unetrir_conv_geom* g, int fam) {
-    return (g->Cin < 8 || g->Cout < 8) ? 5 : fam;
+    return (g->Cin <= 8 || g->Cout <= 8) ? 5 : fam;     // zero-padded stem / head: not part of the MFMA roofline figure
 }
 
 // element-type policies: fp32 and bf16-storage variants share the tap-table construction
