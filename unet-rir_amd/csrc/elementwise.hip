@@ -122,16 +122,23 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
     }
 }
 
-// Block-wide (64 threads, one block per channel) fixed-order sum of the per-slab partials of channel c.
+// Block-wide (256 threads, one block per channel) fixed-order sum of the per-slab partials of channel c.
 __device__ __forceinline__ void slab_sum(const double* __restrict__ part, int nslab, int C, int c, double& s, double& ss) {
-    __shared__ double red[64 * 2];
+    __shared__ double red[256 * 2];
     double a = 0, b = 0;
-    for (int k = threadIdx.x; k < nslab; k += 64) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+#pragma unroll 4
+    for (int k = threadIdx.x; k < nslab; k += 256) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
     red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
     __syncthreads();
-    s = 0; ss = 0;
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 64; ++k) { s += red[k * 2]; ss += red[k * 2 + 1]; }
+    // tree over the 256 partial sums in a fixed pairing order
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            red[threadIdx.x * 2] += red[(threadIdx.x + st) * 2];
+            red[threadIdx.x * 2 + 1] += red[(threadIdx.x + st) * 2 + 1];
+        }
+        __syncthreads();
+    }
+    s = red[0]; ss = red[1];
 }
 
 // stage 2 (BN statistics): mean / biased variance -> affine, saved, moving statistics
@@ -438,7 +445,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
     const ChanPlan pl = chan_plan(P, C);
     hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
                        beta, eps, momentum, moving_mean, moving_var, affine, saved);
     return (int)hipGetLastError();
 }
@@ -461,7 +468,7 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
     hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, relu, dx, lddx);
     return (int)hipGetLastError();
@@ -473,7 +480,7 @@ int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, s
     const ChanPlan pl = chan_plan(P, C);
     hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)ws, pl.nslab, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out);
     return (int)hipGetLastError();
 }
 
@@ -495,7 +502,7 @@ int sigmoid_loss_impl(const float* logits, int ldl, const float* target, int B, 
     const unsigned nb = grid_for((long long)B * H * W, 256, LOSS_BLOCKS);
     hipLaunchKernelGGL(sigmoid_loss_kernel<T>, dim3(nb), dim3(256), 0, s, logits, ldl, target, B, H, W, alpha, inv_norm, pred,
                        dlogits, ldd, (double*)ws);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, (int)nb, alpha, inv_norm, loss_out);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, alpha, inv_norm, loss_out);
     return (int)hipGetLastError();
 }
 

@@ -343,29 +343,43 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// out[i] = sum_s part[s][i] + reg * w[i]
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
-                                     float* __restrict__ out, float reg, const float* __restrict__ w) {
-    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i4 >= n) return;
-    if (i4 + 3 < n) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < nsplit; ++k) {
+// out[i] = sum_s part[s][i] + reg * w[i].  Block = 32 float4 outputs x 8 split groups: group g sums slabs g, g+8, ...
+// (independent loads in flight), then the 8 group sums are added in fixed order -> bit-reproducible.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
+                                                            float* __restrict__ out, float reg, const float* __restrict__ w) {
+    __shared__ float4 red[8][32];
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t i4 = ((size_t)blockIdx.x * 32 + lane) * 4;
+    const bool full = i4 + 3 < n;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (full) {
+#pragma unroll 4
+        for (int k = grp; k < nsplit; k += 8) {
             const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    } else if (i4 < n) {
+        float* sp = &s.x;
+        for (int k = grp; k < nsplit; k += 8)
+            for (size_t i = i4; i < n; ++i) sp[i - i4] += part[(size_t)k * n + i];
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0 || i4 >= n) return;
+#pragma unroll
+    for (int g = 1; g < 8; ++g) {
+        const float4 v = red[g][lane];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (full) {
         if (reg != 0.f) {
             const float4 v = *reinterpret_cast<const float4*>(w + i4);
             s.x += reg * v.x; s.y += reg * v.y; s.z += reg * v.z; s.w += reg * v.w;
         }
         *reinterpret_cast<float4*>(out + i4) = s;
     } else {
-        for (size_t i = i4; i < n; ++i) {
-            float s = 0.f;
-            for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * n + i];
-            if (reg != 0.f) s += reg * w[i];
-            out[i] = s;
-        }
+        const float* sp = &s.x;
+        for (size_t i = i4; i < n; ++i) out[i] = sp[i - i4] + (reg != 0.f ? reg * w[i] : 0.f);
     }
 }
 
@@ -444,8 +458,8 @@ int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* 
 }
 
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s) {
-    const size_t nthreads = (n + 3) / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, part, nsplit, n, out, reg, w);
+    const size_t n4 = (n + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, s, part, nsplit, n, out, reg, w);
     return (int)hipGetLastError();
 }
 

@@ -491,12 +491,14 @@ class UNetEngine:
             # cb1b
             self._bn_relu_bwd(f"dec{l}.cb1b", self.g_ab[l], self.yb[l], self.g_yb[l])
             ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws)
-            ops.colsum(self.g_yb[l], g[f"dec{l}.cb1b.bias"], ws)
+            if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
+                ops.colsum(self.g_yb[l], g[f"dec{l}.cb1b.bias"], ws)
             ops.conv2d_dgrad(self.geo[f"dec{l}.cb1b"], self.g_yb[l], self.wb(f"dec{l}.cb1b.kernel"), self.g_aa[l])
             # cb1a
             self._bn_relu_bwd(f"dec{l}.cb1a", self.g_aa[l], self.ya[l], self.g_ya[l])
             ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws)
-            ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws)
+            if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
+                ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws)
             ops.conv2d_dgrad(self.geo[f"dec{l}.cb1a"], self.g_ya[l], self.wb(f"dec{l}.cb1a.kernel"), self.g_cat[l])
             # Conv2DTranspose
             g_up = self.g_cat[l].slice(c, c)
@@ -533,7 +535,8 @@ class UNetEngine:
         for l in range(self.L, 0, -1):
             self._bn_relu_bwd(f"enc{l}.cb1", g_a, self.y[l], self.g_y[l])
             ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws)
-            ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws)
+            if not self.batchnorm:
+                ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws)
             ops.conv2d_dgrad(self.geo[f"enc{l}.cb1"], self.g_y[l], self.wb(f"enc{l}.cb1.kernel"), self.g_down[l])
             x_in = self.a[l - 1] if l > 1 else self.x4
             ops.conv2d_wgrad(self.geo[f"enc{l}.down"], x_in, self.g_down[l], g[f"enc{l}.down.kernel"], ws, reg=reg,
