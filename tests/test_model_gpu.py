@@ -251,3 +251,21 @@ def test_bf16_train_step_reduces_loss_and_is_deterministic(U):
         l1 = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
     assert np.isfinite(l1) and l1 < l0
     assert float(eng.p["enc1.down.kernel"][..., 2:].abs().max()) == 0.0 and float(eng.p["head.kernel"][2:].abs().max()) == 0.0
+
+
+def test_overlapped_weight_gradient_stream_gives_identical_results(U):
+    """overlap_wgrad=True runs every weight-gradient launch on a side stream; results are bit-identical."""
+    cfg = R.Config(32, 32, 8, 3)
+    Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, 2)
+    t = lambda a: torch.tensor(a).to(DEV)
+    grads = []
+    for ov in (False, True):
+        eng = U.UNetEngine(32, 32, 2, F0=8, device=DEV, overlap_wgrad=ov)
+        eng.load_keras_params(Pn)
+        for _ in range(3):
+            eng.forward(t(spec_in), t(emb), target=t(spec_out), global_batch=2)
+            eng.backward()
+        torch.cuda.synchronize()
+        grads.append(eng.grad.clone())
+    assert torch.equal(grads[0], grads[1])
