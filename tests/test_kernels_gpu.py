@@ -51,6 +51,8 @@ CONV_CASES = [
     (1, 20, 20, 4, 16, 3, 1),      # padded stem (Cin=4)
     (1, 20, 20, 32, 4, 6, 1),      # padded head (Cout=4)
     (3, 1, 1, 256, 64, 1, 1),      # Dense as a 1x1 conv on a 1x1 grid
+    (2, 24, 70, 48, 160, 3, 1),    # patch-staged 3x3 kernel: several tiles in x / y / N, ragged edges, 2 channel chunks
+    (1, 40, 64, 72, 64, 3, 1),
 ]
 
 
@@ -313,6 +315,7 @@ def to_nhwc_bf16(x_nchw, ld, c0, dev):
 BF16_CONV_CASES = [
     (2, 16, 24, 8, 16, 3, 1), (2, 16, 24, 16, 32, 3, 2), (1, 9, 7, 8, 8, 3, 2), (2, 8, 8, 64, 128, 3, 1),
     (1, 10, 12, 40, 72, 3, 1), (1, 12, 12, 64, 8, 6, 1), (2, 16, 16, 128, 64, 3, 1), (1, 32, 32, 8, 64, 3, 1),
+    (2, 24, 70, 48, 160, 3, 1), (1, 40, 64, 136, 64, 3, 1),          # patch-staged kernel: multi-tile, ragged, 3 chunks
 ]
 
 

@@ -1,5 +1,6 @@
 // api.hip - the C ABI (include/unetrir.h): TF padding='same' geometry -> tap tables -> launches.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 #include "kernels.h"
@@ -58,11 +59,22 @@ inline int conv_family(const unetrir_conv_geom* g, int fam) {
 }
 
 // element-type policies: fp32 and bf16-storage variants share the tap-table construction
+// 3x3 stride-1 layers go to the patch-staged kernel (conv3x3.hip) when its 8 x 32 pixel tiles cover the image well
+// (UNETRIR_CONV3X3=0 forces the tap-table kernels, for A/B measurements)
+inline bool use_conv3x3(int k, int stride, int H, int W) {
+    static const bool enabled = [] { const char* e = getenv("UNETRIR_CONV3X3"); return !(e && e[0] == '0'); }();
+    if (!enabled || k != 3 || stride != 1) return false;
+    const double util = (double)H * W / ((double)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32));
+    return util >= 0.7;
+}
+
 struct F32 {
+    static constexpr int is_bf16 = 0;
     using T = float; using Args = IgemmArgs;
     static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd(a, s); }
 };
 struct BF16 {
+    static constexpr int is_bf16 = 1;
     using T = __bf16; using Args = IgemmArgsH;
     static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd_bf16(a, s); }
 };
@@ -71,6 +83,12 @@ struct BF16 {
 template <class P>
 int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, const typename P::T* w, const float* bias,
                   const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s) {
+    if (use_conv3x3(g->k, g->stride, g->H, g->W)) {
+        Conv3Args c{};
+        c.in = x; c.ldi = ldx; c.w = w; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = y; c.ldo = ldy;
+        c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout; c.flip = 0;
+        return launch_conv3x3(c, P::is_bf16, s);
+    }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
     a.g.B = g->B; a.g.PH = sy.out; a.g.PW = sx.out;
@@ -90,6 +108,12 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
 template <class P>
 int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int lddy, const typename P::T* wt, const float* bias,
                     const typename P::T* addend, int ldadd, typename P::T* dx, int lddx, hipStream_t s) {
+    if (use_conv3x3(g->k, g->stride, g->H, g->W)) {     // dgrad of a stride-1 3x3 conv = the same conv with flipped taps
+        Conv3Args c{};
+        c.in = dy; c.ldi = lddy; c.w = wt; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = dx; c.ldo = lddx;
+        c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cout; c.N = g->Cin; c.flip = 1;
+        return launch_conv3x3(c, P::is_bf16, s);
+    }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
     a.g.B = g->B;

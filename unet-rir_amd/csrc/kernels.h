@@ -78,3 +78,15 @@ int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hipStream_t s);
 int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, int Np, hipStream_t s);
+
+// 3x3 stride-1 conv / data gradient with the halo patch staged once in LDS (conv3x3.hip); T = float or __bf16
+struct Conv3Args {
+    const void* in; int ldi;
+    const void* w;            // [N][9][C], element type T
+    const float* bias;        // nullable
+    const void* addend; int ldadd;
+    void* out; int ldo;
+    int B, H, W, C, N;
+    int flip;                 // 0: forward (weight tap t at offset t); 1: data gradient (weight tap 8-t at offset t)
+};
+int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s);
