@@ -66,6 +66,18 @@ def cpu_baseline(F0, H, W, budget_s=45.0):
                       f"oracle/torch_ref.py on torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
 
 
+def traffic(dtype):
+    """HBM bytes per launch of the dominant conv kernel from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction); None if the file is absent.  It is a
+    recorded profile of this same command, not a live measurement (counters cannot be read from inside the process)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)[dtype]
+        return t["traffic_bytes_per_launch"], f'{t["kernel"]}: bytes per launch, profiles/pmc_traffic.json'
+    except Exception:
+        return None, None
+
+
 def run_mode(U, args, dtype, world, rank, device, steps, warmup):
     """Build the engine in one storage mode, run `warmup` untimed and `steps` timed train steps; returns a result dict
     (rank 0) or None.  Timing: barrier + synchronize on both sides, MAX over ranks."""
@@ -118,7 +130,8 @@ def run_mode(U, args, dtype, world, rank, device, steps, warmup):
         ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[dtype]
         res["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic(dtype)[0],
+            "traffic_note": traffic(dtype)[1],
             "kernel": ("igemm_fwd_kernel / wgrad3x3_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv: fwd, dgrad, wgrad)"
                        if dtype == "f32" else
                        "igemm_fwd_bf16_kernel / wgrad3x3_bf16_kernel (bf16 v_mfma_f32_32x32x16_bf16 implicit-GEMM conv: fwd, dgrad, "
