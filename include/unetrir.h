@@ -118,6 +118,18 @@ int unetrir_relu_fwd_f32(const float* x, int ldx, long long P, int C, float* y, 
 int unetrir_relu_bwd_f32(const float* da, int ldda, const float* x, int ldx, long long P, int C,
                          float* dx, int lddx, unetrir_stream_t stream);
 
+/* ---- residual blocks of the ResAE graph (dl_models/res_ae.py:310-371, :453-514): BatchNormalization -> Add ->
+ *      LeakyReLU() (keras default alpha 0.3).  Activation codes: 0 none, 1 ReLU, 2 LeakyReLU(0.3); the `relu` argument of
+ *      unetrir_bn_apply / unetrir_bn_bwd accepts the same codes.
+ *      bn_act_add: y = act(x*scale + shift + addend) (affine NULL = identity, addend NULL = none).
+ *      act_bwd:    g = da * act'(out), derivative chosen by the sign of the activation output.
+ *      add:        y = a + b (n % 4 == 0). */
+int unetrir_bn_act_add_f32(const float* x, int ldx, long long P, int C, const float* affine, int act,
+                           const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream);
+int unetrir_act_bwd_f32(const float* da, int ldda, const float* out, int ldo, long long P, int C, int act, float* g,
+                        int ldg, unetrir_stream_t stream);
+int unetrir_add_f32(const float* a, const float* b, float* y, long long n, unetrir_stream_t stream);
+
 /* ---- boundary layout: the model input is NCHW [B,2,H,W] (north_star); the first conv reads
  *      NHWC padded to 4 channels.  nchw -> [B,H,W,Cpad] with zero fill, and back. */
 int unetrir_nchw_to_nhwc_pad_f32(const float* x, int B, int C, int H, int W, float* y, int Cpad,

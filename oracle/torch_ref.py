@@ -173,6 +173,11 @@ def conv2d_transpose_same(x, w_hwoi, b, stride=2):
     full = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=stride)
     pt, pl = max(kh - stride, 0) // 2, max(kw - stride, 0) // 2
     Ho, Wo = x.shape[2] * stride, x.shape[3] * stride
+    # k < s (the 1x1 stride-2 'valid' layers of ResAE, dl_models/res_ae.py:357): the scatter is shorter than n*s, the
+    # remaining positions receive the bias only
+    eh, ew = max(pt + Ho - full.shape[2], 0), max(pl + Wo - full.shape[3], 0)
+    if eh or ew:
+        full = F.pad(full, (0, ew, 0, eh))
     y = full[:, :, pt:pt + Ho, pl:pl + Wo]
     return y + b.view(1, -1, 1, 1)
 

@@ -48,6 +48,11 @@ _SIGS = {
     "unetrir_relu_fwd_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int, c_stream]),
     "unetrir_relu_bwd_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int,
                                        c_stream]),
+    "unetrir_bn_act_add_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
+                                         C.c_int, c_stream]),
+    "unetrir_act_bwd_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, c_f32p, C.c_int,
+                                      c_stream]),
+    "unetrir_add_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_longlong, c_stream]),
     "unetrir_nchw_to_nhwc_pad_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                                c_stream]),
     "unetrir_head6x6_supported": (C.c_int, [C.c_int]),

@@ -248,7 +248,7 @@ int unetrir_conv2d_wgrad_f32(const unetrir_conv_geom* g, const float* x, int ldx
 
 int unetrir_conv2d_transpose_fwd_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* wt,
                                      const float* bias, float* y, int ldy, unetrir_stream_t stream) {
-    if (!geom_ok(g) || g->stride != 2 || !x || !wt || !y || (g->Cin & 3) || !ld_ok(ldx, g->Cin) || ldy < g->Cout)
+    if (!geom_ok(g) || !x || !wt || !y || (g->Cin & 3) || !ld_ok(ldx, g->Cin) || ldy < g->Cout)
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
@@ -257,7 +257,7 @@ int unetrir_conv2d_transpose_fwd_f32(const unetrir_conv_geom* g, const float* x,
 
 int unetrir_conv2d_transpose_dgrad_f32(const unetrir_conv_geom* g, const float* dy, int lddy, const float* w,
                                        const float* addend, int ldadd, float* dx, int lddx, unetrir_stream_t stream) {
-    if (!geom_ok(g) || g->stride != 2 || !dy || !w || !dx || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || lddx < g->Cin)
+    if (!geom_ok(g) || !dy || !w || !dx || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || lddx < g->Cin)
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(&c), (hipStream_t)stream);
@@ -273,7 +273,7 @@ size_t unetrir_conv2d_transpose_wgrad_ws_bytes(const unetrir_conv_geom* g) {
 int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy, int lddy,
                                        float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
                                        unetrir_stream_t stream) {
-    if (!geom_ok(g) || g->stride != 2 || !x || !dy || !dw || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || (ldx & 3) ||
+    if (!geom_ok(g) || !x || !dy || !dw || (g->Cout & 3) || !ld_ok(lddy, g->Cout) || (ldx & 3) ||
         ldx < g->Cin || (reg_coef != 0.f && !w))
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);

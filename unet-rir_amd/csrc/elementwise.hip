@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float a = xv[k] * sc[k] + sh[k];
-                    const float g = (relu && !(a > 0.f)) ? 0.f : gv[k];
+                    const float g = (relu && !(a > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
                     const float xh = (xv[k] - mu[k]) * rs[k];
                     s0[k] += (double)g; s1[k] += (double)g * (double)xh;
                 }
@@ -193,7 +193,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nsla
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long P, int C,
                                                        const float* __restrict__ affine, int relu,
-                                                       T* __restrict__ y, int ldy) {
+                                                       T* __restrict__ y, int ldy,
+                                                       const T* __restrict__ addend = nullptr, int ldadd = 0) {
     const int CQ = C / 4;
     const long long total = P * CQ;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -209,7 +210,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         } else {
             r = v;
         }
-        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        if (addend) {     // Add() in front of the activation (residual blocks, dl_models/res_ae.py:334, :478)
+            const float4 ad = ld4(addend + (size_t)p * ldadd + c0);
+            r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+        }
+        if (relu) {       // 1: ReLU; 2: keras LeakyReLU() (alpha = 0.3)
+            const float sl = relu == 2 ? 0.3f : 0.f;
+            r.x = r.x > 0.f ? r.x : sl * r.x; r.y = r.y > 0.f ? r.y : sl * r.y;
+            r.z = r.z > 0.f ? r.z : sl * r.z; r.w = r.w > 0.f ? r.w : sl * r.w;
+        }
         st4(y + (size_t)p * ldy + c0, r);
     }
 }
@@ -238,13 +247,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             for (int k = 0; k < 4; ++k) {
                 const float sc = affine[c0 + k], sh = affine[C + c0 + k];
                 const float a = xv[k] * sc + sh;
-                const float g = (relu && !(a > 0.f)) ? 0.f : gv[k];
+                const float g = (relu && !(a > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
                 const float xh = (xv[k] - saved[c0 + k]) * saved[C + c0 + k];
                 out[k] = sc * (g - coef[c0 + k] - xh * coef[C + c0 + k]);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out[k] = (relu && !(xv[k] > 0.f)) ? 0.f : gv[k];
+            for (int k = 0; k < 4; ++k) out[k] = (relu && !(xv[k] > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
         }
         st4(dx + (size_t)p * lddx + c0, make_float4(out[0], out[1], out[2], out[3]));
     }
@@ -617,6 +626,45 @@ int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long
     if (!theta || !g || !m || !v || n <= 0) return UNETRIR_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n,
                        lr_t, beta1, beta2, eps, grad_scale);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = ld4(a + i * 4), v = ld4(b + i * 4);
+        st4(y + i * 4, make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w));
+    }
+}
+
+extern "C" {
+
+/* y = act(x*scale + shift + addend): BatchNormalization -> Add -> LeakyReLU of the residual blocks
+ * (dl_models/res_ae.py:331-336, :475-480).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.3).  affine may be NULL (identity). */
+int unetrir_bn_act_add_f32(const float* x, int ldx, long long P, int C, const float* affine, int act, const float* addend,
+                           int ldadd, float* y, int ldy, unetrir_stream_t stream) {
+    if (!chan_ok(x, ldx, P, C) || !y || ldy < C || (ldy & 3) || act < 0 || act > 2 || (addend && (ldadd < C || (ldadd & 3))))
+        return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, P, C, affine,
+                       act, y, ldy, addend, ldadd);
+    return (int)hipGetLastError();
+}
+
+/* g = da * act'(out) with the derivative decided by the sign of the activation OUTPUT (valid for ReLU / LeakyReLU):
+ * backward of the Add -> LeakyReLU junction, whose result feeds both BatchNorm backward passes. */
+int unetrir_act_bwd_f32(const float* da, int ldda, const float* out, int ldo, long long P, int C, int act, float* g, int ldg,
+                        unetrir_stream_t stream) {
+    if (!chan_ok(out, ldo, P, C) || !chan_ok(da, ldda, P, C) || !g || ldg < C || (ldg & 3) || act < 1 || act > 2) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(P * (C / 4))), dim3(256), 0, (hipStream_t)stream, da, ldda, out, ldo,
+                       P, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act, g, ldg);
+    return (int)hipGetLastError();
+}
+
+/* y = a + b over n floats (n % 4 == 0): gradient accumulation where a tensor has two consumers */
+int unetrir_add_f32(const float* a, const float* b, float* y, long long n, unetrir_stream_t stream) {
+    if (!a || !b || !y || n <= 0 || (n & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 4);
     return (int)hipGetLastError();
 }
 

@@ -191,6 +191,21 @@ def bn_bwd(da: Act, x: Act, gamma, affine, saved, dx: Act, dgamma, dbeta, ws: Wo
               "bn_bwd")
 
 
+def bn_act_add(x: Act, affine, y: Act, act=2, addend: Act = None):
+    """BatchNormalization -> Add -> activation (dl_models/res_ae.py:331-336); act 0 none, 1 ReLU, 2 LeakyReLU(0.3)."""
+    check(_lib.lib().unetrir_bn_act_add_f32(_p(x), x.ld, x.P, x.C, _p(affine), int(act), _p(addend),
+                                            addend.ld if addend is not None else 0, _p(y), y.ld, _stream()), "bn_act_add")
+
+
+def act_bwd(da: Act, out: Act, g: Act, act=2):
+    check(_lib.lib().unetrir_act_bwd_f32(_p(da), da.ld, _p(out), out.ld, out.P, out.C, int(act), _p(g), g.ld, _stream()),
+          "act_bwd")
+
+
+def add(a, b, y):
+    check(_lib.lib().unetrir_add_f32(_p(a), _p(b), _p(y), a.numel(), _stream()), "add")
+
+
 def colsum(x: Act, out, ws: Workspace):
     """Bias gradient: out[c] = sum over pixels."""
     ws.reserve(bn_ws_bytes(x.P, x.C))
