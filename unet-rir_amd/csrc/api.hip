@@ -86,7 +86,9 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
     if (use_conv3x3(g->k, g->stride, g->H, g->W)) {
         Conv3Args c{};
         c.in = x; c.ldi = ldx; c.w = w; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = y; c.ldo = ldy;
-        c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout; c.flip = 0;
+        c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout;
+        static const int nostore = [] { const char* e = getenv("UNETRIR_CONV3X3_NOSTORE"); return (e && e[0] == '1') ? 2 : 0; }();
+        c.flip = nostore;
         return launch_conv3x3(c, P::is_bf16, s);
     }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);

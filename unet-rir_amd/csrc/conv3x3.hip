@@ -33,8 +33,11 @@ __device__ __forceinline__ void mma4(f32x16& acc, const uint4& a, const uint4& b
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
+// bf16: the weight fragment is the A operand, so the accumulator comes out TRANSPOSED (rows/registers = output channel,
+// columns/lanes = pixel): a lane then owns 4 consecutive channels per register quad, which pack into 8-byte LDS writes
+// for the staged epilogue (2-byte global stores straight from the MFMA layout cost 35-40 % of the kernel).
 __device__ __forceinline__ void mma4(f32x16& acc, const uint4& a, const uint4& b, __bf16) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
 }
 
 template <typename T, int BN_>
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Args a) {
     auto load_b = [&](int step) {                     // step = chunk * 9 + tap
         const int ch = step / 9, t = step - ch * 9;
         const int c0 = ch * KE;
-        const int wt = a.flip ? 8 - t : t;
+        const int wt = (a.flip & 1) ? 8 - t : t;
         const bool cok = ch < nchunks && (c0 + q * EPS) < C;
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
@@ -158,6 +161,69 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Args a) {
         }
     }
 
+    if (a.flip & 2) {   // timing experiments only (scripts/micro_conv.py): skip the epilogue stores, keep the accumulators live
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NSUB; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" :: "v"(acc[i][j]));
+#endif
+            }
+        return;
+    }
+    if constexpr (sizeof(T) == 2) {
+        // ---- bf16 epilogue through LDS: acc[i][j] holds D[n = 32j + (r&3) + 8(r>>2) + 4h][pixel = 32i + l31].
+        // (1) + bias, pack 4 consecutive channels -> one ds_write_b64 into this wave's [64 px][BN/2 ch] staging tile;
+        // (2) read it back as 16-byte channel runs of one pixel and store 16 B per lane (coalesced NHWC rows).
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        constexpr int WN = BN_ / 2;                       // channels per wave
+        constexpr int SROW = WN * 2 + 16;                 // staging row stride in bytes (16-byte pad)
+        unsigned char* stage = smem + wave * (64 * SROW); // 8 waves x <= 9216 B, the K loop is over (barrier passed)
+        const int hq = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = 32 * j + 8 * qd + 4 * hq;                   // first of 4 consecutive channels (wave-local)
+                const int n = n0 + wn * WN + nl;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias && n + 3 < a.N) bv = *reinterpret_cast<const float4*>(a.bias + n);
+                else if (a.bias) { float* bp = &bv.x; for (int e = 0; e < 4; ++e) if (n + e < a.N) bp[e] = a.bias[n + e]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    bf16x4 o;
+                    o[0] = (__bf16)(acc[i][j][4 * qd + 0] + bv.x); o[1] = (__bf16)(acc[i][j][4 * qd + 1] + bv.y);
+                    o[2] = (__bf16)(acc[i][j][4 * qd + 2] + bv.z); o[3] = (__bf16)(acc[i][j][4 * qd + 3] + bv.w);
+                    *reinterpret_cast<bf16x4*>(stage + (32 * i + l31) * SROW + nl * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int LPP = WN / 8;                       // lanes per pixel (16 B = 8 channels each)
+        constexpr int PPP = 64 / LPP;                     // pixels per pass
+        const int cq = lane % LPP, pl = lane / LPP;
+        const int n = n0 + wn * WN + cq * 8;
+        T* __restrict__ out = (T*)a.out;
+        const T* __restrict__ addend = (const T*)a.addend;
+#pragma unroll
+        for (int ps = 0; ps < 64 / PPP; ++ps) {
+            const int p = ps * PPP + pl;                  // wave-local pixel: image row 2*wm + (p>>5), column p & 31
+            const int y = y0 + 2 * wm + (p >> 5), x = x0 + (p & 31);
+            if (y >= a.H || x >= a.W || n >= a.N) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(stage + p * SROW + cq * 16);
+            const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+            if (addend) {
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addend + pix * a.ldadd + n);
+                bf16x8 vv = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = (__bf16)((float)vv[e] + (float)ad[e]);
+                v = __builtin_bit_cast(uint4, vv);
+            }
+            *reinterpret_cast<uint4*>(out + pix * a.ldo + n) = v;
+        }
+        return;
+    }
     // epilogue: accumulator col = lane&31 -> n, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> pixel column inside the image row
     T* __restrict__ out = (T*)a.out;
     const T* __restrict__ addend = (const T*)a.addend;
