@@ -31,8 +31,9 @@ template <int BN_, bool UNIFORM>
 __global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a) {
     constexpr int NSUB = BN_ / 64;
     constexpr int NB = BN_ / 32;
-    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LDH];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN_ * LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 smem_h[(BM + BN_) * LDH];     // A tile, B tile; reused by the epilogue
+    __bf16* As = smem_h;
+    __bf16* Bs = smem_h + BM * LDH;
     __shared__ uint32_t s_tap[UNETRIR_MAX_TAPS];
 
     const int tid = threadIdx.x;
@@ -148,43 +149,75 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
+    __syncthreads();      // every wave is done with the A/B tiles: the epilogue stages through the same LDS
 
-    const bool simple = (a.g.SO == 1 && a.g.ooy == 0 && a.g.oox == 0 && a.g.OH == a.g.PH && a.g.OW == a.g.PW);
-    float bias[NSUB];
-    int ncol[NSUB];
+    // ---- epilogue through LDS.  The weight fragment is the MFMA A operand, so acc[i][j] holds
+    // D[n = 32j + (r&3) + 8(r>>2) + 4h][pixel = 32i + (lane&31)]: a lane owns 4 consecutive channels per register quad.
+    // (1) + bias, pack 4 channels -> ds_write_b64 into this wave's [64 px][BN/2 ch] staging tile; (2) read back 16-byte
+    // channel runs of one pixel, add the optional addend, store 16 B per lane (2-byte stores straight from the MFMA layout
+    // cost a third of the kernel).
+    constexpr int WN = BN_ / 2;
+    constexpr int SROW = WN + 8;                          // staging row stride in bf16 elements (16-byte pad)
+    __bf16* stage = smem_h + wave * (64 * SROW);
+    const int hq = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
-        ncol[j] = n0 + wn * (BN_ / 2) + 32 * j + (lane & 31);
-        bias[j] = (a.bias != nullptr && ncol[j] < a.g.N) ? a.bias[ncol[j]] : 0.f;
-    }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int qd = 0; qd < 4; ++qd) {
+            const int nl = 32 * j + 8 * qd + 4 * hq;
+            const int n = n0 + wn * WN + nl;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const long long p = m0 + row;
-            if (p >= M) continue;
-            long long opix;
-            if (simple) {
-                opix = p;
-            } else {
-                const int n = (int)(p / plane);
-                const int rem = (int)(p - (long long)n * plane);
-                const int py = rem / a.g.PW, px = rem - py * a.g.PW;
-                const int oy = py * a.g.SO + a.g.ooy, ox = px * a.g.SO + a.g.oox;
-                if (oy >= a.g.OH || ox >= a.g.OW) continue;
-                opix = ((long long)n * a.g.OH + oy) * a.g.OW + ox;
+                for (int e = 0; e < 4; ++e) if (n + e < a.g.N) bv[e] = a.bias[n + e];
             }
 #pragma unroll
-            for (int j = 0; j < NSUB; ++j) {
-                if (ncol[j] < a.g.N) {
-                    float v = acc[i][j][r] + bias[j];
-                    if (a.addend != nullptr) v += (float)a.addend[opix * a.ldadd + ncol[j]];
-                    a.out[opix * a.g.ldo + ncol[j]] = (__bf16)v;
-                }
+            for (int i = 0; i < 2; ++i) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[i][j][4 * qd + e] + bv[e]);
+                *reinterpret_cast<bf16x4*>(stage + (32 * i + l31) * SROW + nl) = o;
+            }
+        }
+    }
+    __syncthreads();
+    const bool simple = (a.g.SO == 1 && a.g.ooy == 0 && a.g.oox == 0 && a.g.OH == a.g.PH && a.g.OW == a.g.PW);
+    constexpr int LPP = WN / 8;                           // lanes per pixel (8 channels = 16 B each)
+    constexpr int PPP = 64 / LPP;                         // pixels per pass
+    const int cq = lane % LPP, pl = lane / LPP;
+    const int n = n0 + wn * WN + cq * 8;
+#pragma unroll
+    for (int ps = 0; ps < 64 / PPP; ++ps) {
+        const int prow = ps * PPP + pl;
+        const long long p = m0 + wm * 64 + prow;
+        if (p >= M || n >= a.g.N) continue;
+        long long opix;
+        if (simple) {
+            opix = p;
+        } else {
+            const int nimg = (int)(p / plane);
+            const int rem = (int)(p - (long long)nimg * plane);
+            const int py = rem / a.g.PW, px = rem - py * a.g.PW;
+            const int oy = py * a.g.SO + a.g.ooy, ox = px * a.g.SO + a.g.oox;
+            if (oy >= a.g.OH || ox >= a.g.OW) continue;
+            opix = ((long long)nimg * a.g.OH + oy) * a.g.OW + ox;
+        }
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + prow * SROW + cq * 8);
+        if (n + 7 < a.g.N) {
+            if (a.addend != nullptr) {
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(a.addend + opix * a.ldadd + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)ad[e]);
+            }
+            *reinterpret_cast<bf16x8*>(a.out + opix * a.g.ldo + n) = v;
+        } else {          // ragged channel tail (N not a multiple of 8 never happens for activations; kept for safety)
+            for (int e = 0; e < 8 && n + e < a.g.N; ++e) {
+                float f = (float)v[e];
+                if (a.addend != nullptr) f += (float)a.addend[opix * a.ldadd + n + e];
+                a.out[opix * a.g.ldo + n + e] = (__bf16)f;
             }
         }
     }
