@@ -397,19 +397,22 @@ int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-void wgrad3x3_plan(int stride, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx);
+void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx);
+// bf16 patch heights: one barrier pair and one global round trip are amortised over TPH*8 pixels of MFMA work
+#define TPH_S1 8
+#define TPH_S2 4
 
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
     int ns, per;
-    wgrad3x3_plan(stride, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    wgrad3x3_plan_tph(stride == 1 ? TPH_S1 : TPH_S2, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
     const size_t nout = (size_t)a.N * 9 * a.C;
     const bool direct = (ns == 1 && reg == 0.f);
     if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return UNETRIR_EINVAL;
     a.part = direct ? dw : (float*)ws;
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
-    if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 4>), dim3(tiles, ns), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, 2>), dim3(tiles, ns), dim3(256), 0, s, a);
+    if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_S2>), dim3(tiles, ns), dim3(256), 0, s, a);
     int err = (int)hipGetLastError();
     if (err || direct) return err;
     return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);

@@ -118,8 +118,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wgrad3Args a) {
     }
 }
 
+void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx);
 void wgrad3x3_plan(int stride, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx) {
-    const int TPH = stride == 1 ? 4 : 2;
+    wgrad3x3_plan_tph(stride == 1 ? 4 : 2, B, OH, OW, N, C, nsplit, per_split, npy, npx);
+}
+
+void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx) {
     *npy = (OH + TPH - 1) / TPH;
     *npx = (OW + TPW - 1) / TPW;
     const long long G = (long long)B * (*npy) * (*npx);
