@@ -41,6 +41,8 @@ class Config:
     inf_vector_shape: tuple = (2, 16)
     s0: int = 1                  # resize_factor_0[0]
     s: int = 2                   # res_factor[0]
+    mode: int = 0                # feature block: 0 convolutional_block_1, 1 convolutional_block_2, 2 residual_block_1,
+                                 # 3 residual_block_2 (dl_models/u_net.py:280-287, :312-319)
 
     def enc_channels(self) -> List[int]:
         return [self.F0 * (2 ** l) for l in range(self.depth + 1)]
@@ -61,20 +63,31 @@ def same_pads(n_in, k, s):
 
 # --------------------------------------------------------------------------- parameters
 
+def _feature_block_names(cfg, base):
+    """Conv-BN-ReLU units of the per-level feature block (dl_models/u_net.py:324-386): mode 0 keeps the historical names."""
+    if cfg.mode == 0:
+        return [base + (".cb1" if base.startswith("enc") else ".cb1b")]
+    return [base + ".fb.c1", base + ".fb.c2"] + ([base + ".fb.c3"] if cfg.mode == 3 else [])
+
+
 def param_shapes(cfg: Config) -> Dict[str, tuple]:
     """Trainable variables in the order Keras creates them in UNet._build
     (dl_models/u_net.py:201-251).  Names are this repo's; shapes are Keras'."""
     shapes = {}
     ch = cfg.enc_channels()
     cin = 2
+
+    def unit(name, c):
+        shapes[name + ".kernel"] = (3, 3, c, c)
+        shapes[name + ".bias"] = (c,)
+        if cfg.batchnorm:
+            shapes[name + ".gamma"] = (c,)
+            shapes[name + ".beta"] = (c,)
     for l, c in enumerate(ch, start=1):
         shapes[f"enc{l}.down.kernel"] = (cfg.k, cfg.k, cin, c)
         shapes[f"enc{l}.down.bias"] = (c,)
-        shapes[f"enc{l}.cb1.kernel"] = (3, 3, c, c)
-        shapes[f"enc{l}.cb1.bias"] = (c,)
-        if cfg.batchnorm:
-            shapes[f"enc{l}.cb1.gamma"] = (c,)
-            shapes[f"enc{l}.cb1.beta"] = (c,)
+        for u in _feature_block_names(cfg, f"enc{l}"):
+            unit(u, c)
         cin = c
     h5, w5 = cfg.bottleneck_hw()
     n_in = int(np.prod(cfg.inf_vector_shape)) * EMB_DIM
@@ -92,11 +105,8 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
         if cfg.batchnorm:
             shapes[f"dec{l}.cb1a.gamma"] = (c,)
             shapes[f"dec{l}.cb1a.beta"] = (c,)
-        shapes[f"dec{l}.cb1b.kernel"] = (3, 3, c, c)
-        shapes[f"dec{l}.cb1b.bias"] = (c,)
-        if cfg.batchnorm:
-            shapes[f"dec{l}.cb1b.gamma"] = (c,)
-            shapes[f"dec{l}.cb1b.beta"] = (c,)
+        for u in _feature_block_names(cfg, f"dec{l}"):
+            unit(u, c)
     shapes["head.kernel"] = (6, 6, ch[0], 2)
     shapes["head.bias"] = (2,)
     return shapes
@@ -252,6 +262,22 @@ def conv_block_1(x, P, name, cfg, state, training, inter, q=_ident, qw=_ident):
     return y
 
 
+def feature_block(x, P, base, cfg, state, training, inter, q, qw):
+    """mode 0: convolutional_block_1; 1: convolutional_block_2 (dl_models/u_net.py:373-386); 2: residual_block_1
+    (:324-339, two units + identity Add, no activation after the Add); 3: residual_block_2 (:341-361, third unit on the skip)."""
+    names = _feature_block_names(cfg, base)
+    if cfg.mode == 0:
+        return conv_block_1(x, P, names[0], cfg, state, training, inter, q, qw)
+    a = conv_block_1(x, P, names[0], cfg, state, training, inter, q, qw)
+    b = conv_block_1(a, P, names[1], cfg, state, training, inter, q, qw)
+    if cfg.mode == 1:
+        return b
+    if cfg.mode == 2:
+        return q(b + x)
+    c = conv_block_1(x, P, names[2], cfg, state, training, inter, q, qw)
+    return q(b + c)
+
+
 def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
             dropout_mask: Optional[torch.Tensor] = None, bn_state=None, inter=None, storage=None):
     """UNet._build graph (dl_models/u_net.py:201-251), mode 0.
@@ -270,7 +296,7 @@ def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
         x = q(conv2d_same(x, qw(P[f"enc{l}.down.kernel"]), P[f"enc{l}.down.bias"], stride))
         if inter is not None:
             inter[f"enc{l}.down"] = x
-        x = conv_block_1(x, P, f"enc{l}.cb1", cfg, bn_state, training, inter, q, qw)
+        x = feature_block(x, P, f"enc{l}", cfg, bn_state, training, inter, q, qw)
         skips.append(x)
     # vector_block (dl_models/u_net.py:253-263)
     B = spec.shape[0]
@@ -294,7 +320,7 @@ def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
             inter[f"dec{l}.up"] = x
         x = q(torch.cat([skips[l - 1], x], dim=1))       # concatenate([skip, x]) (:308)
         x = conv_block_1(x, P, f"dec{l}.cb1a", cfg, bn_state, training, inter, q, qw)
-        x = conv_block_1(x, P, f"dec{l}.cb1b", cfg, bn_state, training, inter, q, qw)
+        x = feature_block(x, P, f"dec{l}", cfg, bn_state, training, inter, q, qw)
     # UpSampling2D((1,1)) is the identity; Conv2D(2,(6,6),'same') + sigmoid (:247-249)
     x = conv2d_same(x, P["head.kernel"], P["head.bias"], 1)      # logits stay fp32 in every mode
     if storage == "bf16":

@@ -269,3 +269,43 @@ def test_overlapped_weight_gradient_stream_gives_identical_results(U):
         torch.cuda.synchronize()
         grads.append(eng.grad.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("mode,bn", [(0, True), (1, True), (2, True), (3, True), (2, False)])
+def test_feature_block_modes_on_graph_engine(U, mode, bn):
+    """dl_models/u_net.py modes 0-3 (convolutional_block_1/2, residual_block_1/2) on UNetGraphEngine vs the oracle."""
+    H, W, F0, B = 32, 48, 4, 2
+    cfg = R.Config(H, W, F0, 3, 4, bn, mode=mode)
+    Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
+    h5, w5 = cfg.bottleneck_hw()
+    mask = (detrand.uniform("gmask", (B, h5 * w5 * 16)) >= 0.3).astype(np.float64) / 0.7
+    loss, dl, pred, grads = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, 0.9, B, 1, mask, torch.float64)
+    eng = U.UNetGraphEngine(H, W, B, F0=F0, k=3, mode=mode, batchnorm=bn, device=DEV)
+    assert set(eng.specs) == set(grads)
+    eng.load_keras_params(Pn)
+    t = lambda a, dt=None: torch.tensor(a, dtype=dt).to(DEV)
+    eng.forward(t(spec_in), t(emb), dropout_mask=t(mask, torch.float32), target=t(spec_out), global_batch=B)
+    eng.backward()
+    eng.reg_loss()
+    torch.cuda.synchronize()
+    check_against_oracle(eng, (loss, dl, pred, grads, None))
+
+
+def test_graph_engine_mode0_equals_hand_schedule(U):
+    """The generic executor and the hand-scheduled engine run the same kernels: identical predictions, gradients to 1e-6."""
+    H, W, F0, B = 32, 32, 8, 2
+    cfg = R.Config(H, W, F0, 3)
+    Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
+    t = lambda a: torch.tensor(a).to(DEV)
+    e1 = U.UNetEngine(H, W, B, F0=F0, device=DEV); e1.load_keras_params(Pn)
+    e2 = U.UNetGraphEngine(H, W, B, F0=F0, device=DEV); e2.load_keras_params(Pn)
+    for e in (e1, e2):
+        e.forward(t(spec_in), t(emb), target=t(spec_out), global_batch=B)
+        e.backward()
+    torch.cuda.synchronize()
+    assert float((e1.pred - e2.pred).abs().max()) <= 1e-6
+    g1, g2 = e1.export_keras_grads(), e2.export_keras_grads()
+    for n in g1:
+        assert float((g1[n] - g2[n]).abs().max()) <= 1e-6 * (float(g1[n].abs().max()) + 1e-12) + 1e-9, n

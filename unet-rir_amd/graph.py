@@ -1,0 +1,365 @@
+"""A small static-graph executor over the HIP kernels (fp32): the graph is built once as a list of (forward, backward)
+closures over preallocated NHWC buffers; forward runs the list, backward runs it in reverse.
+
+Used for the operator graphs that are not hand-scheduled in engine.py: ResAE (dl_models/res_ae.py) and the U-Net feature
+block modes 1-3 (dl_models/u_net.py:324-386).  A tensor with several consumers gets its gradient from several writers:
+the first one writes, the others accumulate in place (conv data gradients through the kernels' `addend` epilogue).
+Parameters, gradients and Adam moments live in flat buffers ordered by backward completion, as in engine.py.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from .ops import Act
+from .engine import ALIGN, BN_EPS, BN_MOMENTUM, L2_COEF, DROPOUT_P, ParamSpec
+
+RELU, LEAKY = 1, 2       # activation codes of the C ABI (LeakyReLU: keras default alpha 0.3)
+
+
+class Node:
+    """An activation buffer (or a channel slice of one) and the buffer of its gradient."""
+    __slots__ = ("a", "g", "g_set", "needs_grad", "children")
+
+    def __init__(self, a: Act, needs_grad=True, g: Act = None):
+        self.a = a
+        self.g = g if g is not None else (Act(torch.empty_like(a.base)) if needs_grad else None)
+        self.g_set = False
+        self.needs_grad = needs_grad
+        self.children = []           # channel-slice views: written whenever this node's gradient is written
+
+
+class GraphEngine:
+    def __init__(self, B, device="cuda:0", n_replicas=1):
+        self.B = B
+        self.device = torch.device(device)
+        self.n_replicas = n_replicas
+        self.nodes, self.specs_fwd, self.ops = [], [], []
+        self.bn_names, self.l2_names = [], []
+        self.moving = {}
+        self.masks = {}              # dropout keep masks by name (None = no dropout)
+        self.ws = ops.Workspace(self.device, 1 << 20)
+        self._p, self._g, self._pt = {}, {}, {}
+        self.adam_t = 0
+
+    # ------------------------------------------------------------------ construction helpers
+    def _param(self, name, shape, kind, keras_shape, l2=False):
+        self.specs_fwd.append(ParamSpec(name, shape, kind, keras_shape))
+        if l2:
+            self.l2_names.append(name)
+
+    def _reg(self, node):
+        self.nodes.append(node)
+        return node
+
+    def _new(self, h, w, c, needs_grad=True):
+        return self._reg(Node(ops.new_act(self.B, h, w, c, self.device), needs_grad))
+
+    def _view(self, parent: Node, c0, c):
+        """Channel slice [c0, c0+c) of a buffer (one half of a skip concat)."""
+        v = self._reg(Node(parent.a.slice(c0, c), True, parent.g.slice(c0, c)))
+        parent.children.append(v)
+        return v
+
+    def _emit(self, node, writer):
+        """writer(dst, addend): dst = value (+ addend).  First writer of a gradient writes, later ones accumulate."""
+        if not node.needs_grad:
+            return
+        writer(node.g, node.g if node.g_set else None)
+        node.g_set = True
+        for ch in node.children:
+            ch.g_set = True
+
+    def _conv(self, x: Node, name, cout, k, stride, transpose=False, followed_by_bn=True, pad_in=0, pad_out=0, l2=True,
+              dense=False, out: Node = None):
+        """Conv2D / Conv2DTranspose (TF 'same'; 1x1 'valid' is the same geometry) + bias."""
+        B, cin = self.B, x.a.C
+        if transpose:
+            H, W = x.a.H * stride, x.a.W * stride
+        else:
+            H, W = -(-x.a.H // stride), -(-x.a.W // stride)
+        co = pad_out if pad_out else cout
+        y = out if out is not None else self._new(H, W, co)
+        kname, bname = name + ".kernel", name + ".bias"
+        real_in = 2 if pad_in else cin
+        if transpose:      # primary layout [Cin][k][k][Cout]; keras (k,k,Cout,Cin)
+            self._param(kname, (cin, k, k, co), "convT_padout" if pad_out else "convT", (k, k, cout, real_in), l2)
+        else:              # [Cout][k][k][Cin]; keras (k,k,Cin,Cout) or Dense [in,out]
+            kind = "conv_padin" if pad_in else ("conv_padout" if pad_out else "conv")
+            self._param(kname, (co, k, k, cin), kind, (cin, cout) if dense else (k, k, real_in, cout), l2)
+        self._param(bname, (co,), "bias_pad" if pad_out else "bias", (cout,))
+        g = ops.geom(B, x.a.H, x.a.W, cin, co, k, stride)
+        reg = lambda: (2.0 * L2_COEF / self.n_replicas) if l2 else 0.0
+
+        def fwd():
+            if transpose:
+                ops.conv2d_transpose_fwd(g, x.a, self._pt[kname], self._p[bname], y.a)
+            else:
+                ops.conv2d_fwd(g, x.a, self._p[kname], self._p[bname], y.a)
+
+        def bwd():
+            if transpose:
+                ops.conv2d_transpose_wgrad(g, x.a, y.g, self._g[kname], self.ws, reg=reg(), w=self._p[kname])
+            else:
+                ops.conv2d_wgrad(g, x.a, y.g, self._g[kname], self.ws, reg=reg(), w=self._p[kname])
+            if not followed_by_bn:        # a bias in front of BatchNorm has an identically zero gradient
+                ops.colsum(y.g, self._g[bname], self.ws)
+            if transpose:
+                self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, self._p[kname], dst, addend=add))
+            else:
+                self._emit(x, lambda dst, add: ops.conv2d_dgrad(g, y.g, self._pt[kname], dst, addend=add))
+        self.ops.append((fwd, bwd))
+        return y
+
+    def _bn_act(self, x: Node, name, act, addend: Node = None, out: Node = None, batchnorm=True):
+        """BatchNormalization (+ Add) (+ activation).  x must have this op as its only consumer."""
+        c = x.a.C
+        y = out if out is not None else self._new(x.a.H, x.a.W, c)
+        if batchnorm:
+            self._param(name + ".gamma", (c,), "gamma", (c,))
+            self._param(name + ".beta", (c,), "beta", (c,))
+            self.bn_names.append(name)
+            aff = torch.empty(2 * c, dtype=torch.float32, device=self.device)
+            saved = torch.empty(2 * c, dtype=torch.float32, device=self.device)
+            mm = torch.zeros(c, dtype=torch.float32, device=self.device)
+            mv = torch.ones(c, dtype=torch.float32, device=self.device)
+            self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"] = mm, mv
+        gj = Act(torch.empty_like(x.a.base)) if addend is not None else None
+
+        def fwd():
+            if batchnorm:
+                ops.bn_stats(x.a, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, self.ws, mm, mv, BN_EPS, BN_MOMENTUM)
+            ops.bn_act_add(x.a, aff if batchnorm else None, y.a, act, addend.a if addend is not None else None)
+
+        def bwd():
+            if addend is None and batchnorm:
+                ops.bn_bwd(y.g, x.a, None, aff, saved, x.g, self._g[name + ".gamma"], self._g[name + ".beta"], self.ws, relu=act)
+            elif addend is None:
+                ops.act_bwd(y.g, y.a, x.g, act)
+            else:      # junction y = act(bn(x) + addend): g = dy * act'(y) feeds both branches
+                if act:
+                    ops.act_bwd(y.g, y.a, gj, act)
+                    gsrc = gj
+                else:
+                    gsrc = y.g
+                if batchnorm:
+                    ops.bn_bwd(gsrc, x.a, None, aff, saved, x.g, self._g[name + ".gamma"], self._g[name + ".beta"], self.ws, relu=0)
+                else:
+                    ops.bn_act_add(gsrc, None, x.g, 0, None)
+                self._emit(addend, lambda dst, add: ops.bn_act_add(gsrc, None, dst, 0, add))
+            x.g_set = True
+        self.ops.append((fwd, bwd))
+        return y
+
+    def _add(self, x: Node, y: Node, out: Node = None):
+        """Add()([x, y]) without activation (dl_models/u_net.py:229, :337, :359)."""
+        z = out if out is not None else self._new(x.a.H, x.a.W, x.a.C)
+
+        def fwd():
+            ops.bn_act_add(x.a, None, z.a, 0, y.a)
+
+        def bwd():
+            self._emit(x, lambda dst, add: ops.bn_act_add(z.g, None, dst, 0, add))
+            self._emit(y, lambda dst, add: ops.bn_act_add(z.g, None, dst, 0, add))
+        self.ops.append((fwd, bwd))
+        return z
+
+    def _dense(self, x: Node, name, n_out):
+        return self._conv(x, name, n_out, 1, 1, False, followed_by_bn=False, l2=False, dense=True)
+
+    def _dropout(self, x: Node, which):
+        """Dropout(.3) with an externally supplied keep mask self.masks[which] (already scaled by 1/(1-p))."""
+        y = self._new(x.a.H, x.a.W, x.a.C)
+        self.masks.setdefault(which, None)
+
+        def fwd():
+            m = self.masks[which]
+            if m is None:
+                y.a.base.copy_(x.a.base)
+            else:
+                ops.mul(x.a.base, m, y.a.base)
+
+        def bwd():
+            m = self.masks[which]
+            if m is None:
+                x.g.base.copy_(y.g.base)
+            else:
+                ops.mul(y.g.base, m, x.g.base)
+            x.g_set = True
+        self.ops.append((fwd, bwd))
+        return y
+
+    def _embedding(self, n_idx, name="embedding", vocab=2000, dim=256):
+        """Embedding(2000, 256) -> Flatten; returns a [B,1,1,n_idx*dim] node."""
+        B, dev = self.B, self.device
+        self._param(name, (vocab, dim), "embedding", (vocab, dim))
+        self.emb_idx = torch.zeros(B * n_idx, dtype=torch.int32, device=dev)
+        emb_out = torch.empty((B * n_idx, dim), dtype=torch.float32, device=dev)
+        g_emb_out = torch.empty_like(emb_out)
+        node = self._reg(Node(Act(emb_out.view(B, 1, 1, n_idx * dim)), True, Act(g_emb_out.view(B, 1, 1, n_idx * dim))))
+
+        def fwd():
+            ops.embedding_fwd(self.emb_idx, self._p[name], emb_out)
+
+        def bwd():
+            ops.embedding_bwd(self.emb_idx, g_emb_out, self._g[name])
+        self.ops.append((fwd, bwd))
+        return node
+
+    def _reshape(self, x: Node, h, w, c):
+        """Reshape of a [B,1,1,h*w*c] node to NHWC [B,h,w,c] (Keras Reshape is NHWC): a view, gradients alias."""
+        v = self._reg(Node(Act(x.a.base.view(self.B, h, w, c)), True, Act(x.g.base.view(self.B, h, w, c))))
+
+        def bwd():
+            x.g_set = True
+        self.ops.append((lambda: None, bwd))
+        return v
+
+    # ------------------------------------------------------------------ parameters
+    def _finalize_params(self):
+        specs = list(reversed(self.specs_fwd))          # backward completion order
+        off = 0
+        for s_ in specs:
+            s_.offset = off
+            off += -(-s_.numel // ALIGN) * ALIGN
+        self.specs = OrderedDict((s_.name, s_) for s_ in specs)
+        dev = self.device
+        self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        for n, s_ in self.specs.items():
+            self._p[n] = self.theta[s_.offset:s_.offset + s_.numel].view(s_.shape)
+            self._g[n] = self.grad[s_.offset:s_.offset + s_.numel].view(s_.shape)
+        self.p, self.g = self._p, self._g
+        self._tnames = [n for n, s_ in self.specs.items() if s_.kind.startswith("conv")]
+        toff = sum(-(-self.specs[n].numel // ALIGN) * ALIGN for n in self._tnames)
+        self.theta_t = torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
+        o = 0
+        for n in self._tnames:
+            k_ = self.specs[n].numel
+            self._pt[n] = self.theta_t[o:o + k_]
+            o += -(-k_ // ALIGN) * ALIGN
+
+    def refresh_transposed(self):
+        for n in self._tnames:
+            s_ = self.specs[n]
+            ops.transpose_weight(self._p[n], self._pt[n], s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3])
+
+    def load_keras_params(self, params):
+        """params: name -> array in Keras layout (HWIO Conv2D, HWOI Conv2DTranspose, [in,out] Dense)."""
+        with torch.no_grad():
+            for n, s_ in self.specs.items():
+                a = torch.as_tensor(params[n]).to(torch.float32)
+                if tuple(a.shape) != s_.keras_shape:
+                    raise ValueError(f"{n}: expected Keras shape {s_.keras_shape}, got {tuple(a.shape)}")
+                t = self._p[n]
+                if s_.kind in ("conv", "convT"):
+                    if a.dim() == 4:
+                        t.copy_(a.permute(3, 0, 1, 2).to(self.device))
+                    else:
+                        t.copy_(a.t().reshape(t.shape).to(self.device))
+                elif s_.kind in ("conv_padin", "convT_padout"):
+                    t.zero_(); t[..., :2].copy_(a.permute(3, 0, 1, 2).to(self.device))
+                elif s_.kind == "conv_padout":
+                    t.zero_(); t[:2].copy_(a.permute(3, 0, 1, 2).to(self.device))
+                elif s_.kind == "bias_pad":
+                    t.zero_(); t[:2].copy_(a.to(self.device))
+                else:
+                    t.copy_(a.to(self.device))
+
+    def _to_keras(self, views):
+        out = {}
+        for n, s_ in self.specs.items():
+            t = views[n].detach()
+            if s_.kind in ("conv", "convT"):
+                a = t.permute(1, 2, 3, 0) if len(s_.keras_shape) == 4 else t.reshape(t.shape[0], -1).t()
+            elif s_.kind in ("conv_padin", "convT_padout"):
+                a = t[..., :2].permute(1, 2, 3, 0)
+            elif s_.kind == "conv_padout":
+                a = t[:2].permute(1, 2, 3, 0)
+            elif s_.kind == "bias_pad":
+                a = t[:2]
+            else:
+                a = t
+            out[n] = a.contiguous().cpu()
+        return out
+
+    def export_keras_grads(self):
+        return self._to_keras(self._g)
+
+    def export_keras_params(self):
+        return self._to_keras(self._p)
+
+    def reset_parameters(self, generator=None):
+        """Keras defaults: glorot_uniform kernels, zero biases, gamma 1, beta 0, Embedding U(-0.05, 0.05)."""
+        with torch.no_grad():
+            for n, s_ in self.specs.items():
+                t, ks = self._p[n], s_.keras_shape
+                if s_.kind == "embedding":
+                    t.copy_((torch.rand(s_.shape, generator=generator) * 0.1 - 0.05).to(self.device))
+                elif s_.kind.startswith("conv"):
+                    rf = ks[0] * ks[1] if len(ks) == 4 else 1
+                    fan_in, fan_out = (ks[2] * rf, ks[3] * rf) if len(ks) == 4 else ks
+                    lim = math.sqrt(6.0 / (fan_in + fan_out))
+                    w = ((torch.rand(s_.shape, generator=generator) * 2 - 1) * lim).to(self.device)
+                    if s_.kind in ("conv_padin", "convT_padout"):
+                        w[..., 2:] = 0
+                    if s_.kind == "conv_padout":
+                        w[2:] = 0
+                    t.copy_(w)
+                elif s_.kind == "gamma":
+                    t.fill_(1.0)
+                else:
+                    t.zero_()
+
+    # ------------------------------------------------------------------ step pieces
+    def run_forward(self):
+        self.refresh_transposed()
+        for fwd, _ in self.ops:
+            fwd()
+
+    def backward(self):
+        for _, bwd in reversed(self.ops):
+            bwd()
+        for node in self.nodes:          # next step: the first writer of every gradient writes again
+            node.g_set = False
+
+    def loss_or_sigmoid(self, logits: Node, target, global_batch, alpha):
+        if target is not None:
+            gb = self.B if global_batch is None else global_batch
+            ops.sigmoid_loss(logits.a, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, logits.g, self.loss_out, self.ws)
+            logits.g_set = True
+        else:
+            ops.sigmoid_nchw(logits.a, self.pred)
+        return self.pred
+
+    def _alloc_outputs(self):
+        dev = self.device
+        self.pred = torch.empty((self.B, 2, self.H, self.W), dtype=torch.float32, device=dev)
+        self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.reg_out = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def reg_loss(self):
+        """sum(model.losses) / replicas evaluated on device into reg_out[0]."""
+        first = True
+        for n in self.l2_names:
+            s_ = self.specs[n]
+            ops.sumsq(self.theta[s_.offset:s_.offset + s_.numel], L2_COEF / self.n_replicas, self.reg_out, not first, self.ws)
+            first = False
+        if first:
+            self.reg_out.zero_()
+        return self.reg_out
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        self.adam_t += 1
+        t = self.adam_t
+        ops.adam(self.theta, self.grad, self.adam_m, self.adam_v, lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t),
+                 beta1, beta2, eps, 1.0)
+
+    def dropout_mask(self, n, generator=None):
+        return (torch.rand((self.B, n), device=self.device, generator=generator) >= DROPOUT_P).to(torch.float32) / (1.0 - DROPOUT_P)
+
+    def n_params(self):
+        return sum(int(math.prod(s_.keras_shape)) for s_ in self.specs.values())

@@ -69,7 +69,8 @@ class UNet(nn.Module):
         self.res_factor = [2, 2] if res_factor is None else list(res_factor)
         self.resize_factor_0 = [1, 1] if resize_factor_0 is None else list(resize_factor_0)
         if mode != 0:
-            raise NotImplementedError("only mode=0 (convolutional_block_1, dl_models/u_net.py:363-371) is implemented")
+            raise NotImplementedError("the nn.Module wrapper drives the hand-scheduled mode-0 engine; modes 1-3 "
+                                      "(dl_models/u_net.py:324-386) run on unet_rir_amd.UNetGraphEngine")
         if self.res_factor != [2, 2] or self.resize_factor_0 != [1, 1]:
             raise NotImplementedError("only res_factor=[2,2], resize_factor_0=[1,1] are implemented")
         shp = tuple(input_shape)
