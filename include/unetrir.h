@@ -83,6 +83,13 @@ int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* 
                                        const float* w, void* ws, size_t ws_bytes,
                                        unetrir_stream_t stream);
 
+/* Dense(N) (dl_models/u_net.py:259, Flatten -> Dense) on a small batch: y[B][N] = x[B][K] . w[N][K]^T + bias (bias nullable),
+ * split-K over the workgroups so the weight matrix streams from every CU; ws >= unetrir_dense_fwd_ws_bytes.  The data
+ * gradient is the same call with the [K][N] weight copy and no bias. */
+size_t unetrir_dense_fwd_ws_bytes(int B, int K, int N);
+int unetrir_dense_fwd_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K,
+                          int N, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+
 /* [N][T][C] -> [C][T][N] (swap the channel roles of a conv kernel, taps kept). */
 int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C,
                                  unetrir_stream_t stream);

@@ -463,3 +463,18 @@ def test_head_and_loss_bf16(U):
     ops.head6x6_wgrad(xa, dl, dw, ws)
     torch.cuda.synchronize()
     close(dw[:2], w2.grad.permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "head wgrad (bf16 in)")
+
+
+@pytest.mark.parametrize("B,K,N", [(32, 8192, 4096), (3, 520, 72), (4, 4096, 8192)])
+def test_dense_split_k(U, B, K, N):
+    """Dense on a small batch through the split-K entry point (dl_models/u_net.py:259) and its data gradient."""
+    ops = U.ops
+    x = torch.tensor(detrand.uniform(f"dx{B,K}", (B, K), -1, 1))
+    w = torch.tensor(detrand.uniform(f"dw{K,N}", (N, K), -1, 1)) * 0.05
+    b = torch.tensor(detrand.uniform(f"db{N}", (N,), -1, 1))
+    xa = ops.Act(x.view(B, 1, 1, K).to(DEV))
+    ya = ops.Act(torch.full((B, 1, 1, N), 7.0, device=DEV))
+    ws = ops.Workspace(DEV)
+    ops.dense_fwd(xa, w.to(DEV), b.to(DEV), ya, ws)
+    torch.cuda.synchronize()
+    close(ya.base.view(B, N), x.double() @ w.double().t() + b.double(), 2e-6 * math.sqrt(K) + 1e-6, "dense fwd")

@@ -35,6 +35,9 @@ _SIGS = {
     "unetrir_conv2d_transpose_wgrad_ws_bytes": (C.c_size_t, [C.POINTER(ConvGeom)]),
     "unetrir_conv2d_transpose_wgrad_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
                                                      C.c_float, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_dense_fwd_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "unetrir_dense_fwd_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_transpose_weight_f32": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_stream]),
     "unetrir_bn_ws_bytes": (C.c_size_t, [C.c_longlong, C.c_int]),
     "unetrir_bn_stats_f32": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,

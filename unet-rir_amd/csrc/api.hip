@@ -354,6 +354,16 @@ int unetrir_transpose_cast_weight_bf16(const float* w, unetrir_bf16* wt, int N, 
     return launch_transpose_cast_weight(w, wt, N, T, C, Np, (hipStream_t)stream);
 }
 
+/* Dense(N) (dl_models/u_net.py:259) on a small batch: y[B][N] = x[B][K] . w[N][K]^T + bias, split-K so that the 134 MB
+ * weight matrix streams from every CU.  The data gradient is the same call with the transposed weight copy and no bias. */
+size_t unetrir_dense_fwd_ws_bytes(int B, int K, int N) { return dense_fwd_ws_bytes(B, K, N); }
+
+int unetrir_dense_fwd_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
+                          void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    if (!x || !w || !y || !ws || B <= 0 || K <= 0 || N <= 0 || (K & 3) || ldx < K || (ldx & 3) || ldy < N) return UNETRIR_EINVAL;
+    return launch_dense_fwd(x, ldx, w, bias, y, ldy, B, K, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C, unetrir_stream_t stream) {
     if (!w || !wt || N <= 0 || T <= 0 || C <= 0) return UNETRIR_EINVAL;
     return launch_transpose_weight(w, wt, N, T, C, (hipStream_t)stream);

@@ -56,14 +56,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     const int IH = a.g.IH, IW = a.g.IW, ldi = a.g.ldi;
     const int ldw = a.g.wtaps * C;
     const int Ktot = ntaps * C;
-    const int nch = (Ktot + BK - 1) / BK;
+    int nch = (Ktot + BK - 1) / BK;
+    int ch0 = 0;
+    if (a.ksplit > 1) {      // split-K (small pixel counts, e.g. the Dense layer): this block owns chunks [ch0, nch)
+        const int per = (nch + a.ksplit - 1) / a.ksplit;
+        ch0 = blockIdx.y * per;
+        nch = min(nch, ch0 + per);
+    }
 
     // loader mapping: 8 threads cover the 32 k-values of one row; 32 rows per pass
     const int quad = tid & 7, lrow = tid >> 3;
     // (tap, channel) of the k-quad being staged.  UNIFORM (C % 32 == 0): a stage never straddles a tap, so the
     // tap index and the channel base are wave-uniform scalars and only quad*4 is per lane.
-    int kt = UNIFORM ? 0 : (quad * 4) / C;
-    int kc = UNIFORM ? 0 : (quad * 4) % C;
+    int kt = (ch0 * BK + (UNIFORM ? 0 : quad * 4)) / C;
+    int kc = (ch0 * BK + (UNIFORM ? 0 : quad * 4)) % C;
 
     __syncthreads();   // s_tap visible
 
@@ -138,8 +144,8 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
     const int arow = wm * 64 + (lane & 31), brow = wn * (BN_ / 2) + (lane & 31);
     const int koff = (lane >> 5) * 4;
 
-    for (int ch = 0; ch < nch; ++ch) {
-        if (ch) __syncthreads();
+    for (int ch = ch0; ch < nch; ++ch) {
+        if (ch != ch0) __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[(lrow + 32 * j) * LDS_LD + quad * 4]) = ra[j];
 #pragma unroll
@@ -177,6 +183,22 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
         }
     }
 
+    if (a.ksplit > 1) {      // raw partial sums; bias / reduction happen in splitk_rows_reduce_kernel
+        float* part = a.part + (size_t)blockIdx.y * M * a.g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long p = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (p >= M) continue;
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) {
+                    const int n = n0 + wn * (BN_ / 2) + 32 * j + (lane & 31);
+                    if (n < a.g.N) part[p * a.g.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     // ---- epilogue: accumulator (col = lane&31 -> n, row = (r&3)+8*(r>>2)+4*(lane>>5) -> pixel)
     const bool simple = (a.g.SO == 1 && a.g.ooy == 0 && a.g.oox == 0 && a.g.OH == a.g.PH && a.g.OW == a.g.PW);
     float bias[NSUB];
@@ -408,14 +430,49 @@ int launch_igemm_fwd(const IgemmArgs& a, hipStream_t s) {
     if (M <= 0 || a.g.N <= 0) return 0;
     const long long mt = (M + BM - 1) / BM;
     const bool uniform = (a.g.C % BK) == 0;
+    const unsigned ks = a.ksplit > 1 ? (unsigned)a.ksplit : 1u;
     if (a.g.N > 64) {
         const long long nwg = mt * ((a.g.N + 127) / 128);
-        if (uniform) hipLaunchKernelGGL((igemm_fwd_kernel<128, true>), dim3((unsigned)nwg), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((igemm_fwd_kernel<128, false>), dim3((unsigned)nwg), dim3(256), 0, s, a);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_kernel<128, true>), dim3((unsigned)nwg, ks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<128, false>), dim3((unsigned)nwg, ks), dim3(256), 0, s, a);
     } else {
-        if (uniform) hipLaunchKernelGGL((igemm_fwd_kernel<64, true>), dim3((unsigned)mt), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((igemm_fwd_kernel<64, false>), dim3((unsigned)mt), dim3(256), 0, s, a);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_kernel<64, true>), dim3((unsigned)mt, ks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_fwd_kernel<64, false>), dim3((unsigned)mt, ks), dim3(256), 0, s, a);
     }
+    return (int)hipGetLastError();
+}
+
+// y[p][n] = bias[n] + sum_s part[s][p][n]   (fixed order)
+__global__ void splitk_rows_reduce_kernel(const float* __restrict__ part, int nsplit, long long M, int N,
+                                          const float* __restrict__ bias, float* __restrict__ y, int ldy) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * N) return;
+    const long long p = i / N;
+    const int n = (int)(i - p * N);
+    float s = bias ? bias[n] : 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * M * N + i];
+    y[p * ldy + n] = s;
+}
+
+#define DENSE_KSPLIT 16
+size_t dense_fwd_ws_bytes(int B, int K, int N) { (void)K; return (size_t)DENSE_KSPLIT * B * N * sizeof(float); }
+
+// Dense(N) on a small batch: y[B][N] = x[B][K] . w[N][K]^T + bias.  The weight matrix is streamed once; with only B rows
+// there are N/128 output tiles, so the K dimension is split 16 ways to put >= 2 workgroups on every CU.
+int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
+                     void* ws, size_t ws_bytes, hipStream_t s) {
+    if (ws_bytes < dense_fwd_ws_bytes(B, K, N)) return UNETRIR_EINVAL;
+    IgemmArgs a{};
+    a.g.B = B; a.g.PH = 1; a.g.PW = 1; a.g.IH = 1; a.g.IW = 1; a.g.C = K; a.g.ldi = ldx;
+    a.g.OH = 1; a.g.OW = 1; a.g.N = N; a.g.ldo = ldy; a.g.SI = 1; a.g.SO = 1;
+    a.g.ntaps = 1; a.g.wtaps = 1; a.g.tap[0] = 0;
+    a.in = x; a.w = w; a.out = y;
+    a.ksplit = DENSE_KSPLIT; a.part = (float*)ws;
+    int err = launch_igemm_fwd(a, s);
+    if (err) return err;
+    const long long tot = (long long)B * N;
+    hipLaunchKernelGGL(splitk_rows_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)ws,
+                       DENSE_KSPLIT, (long long)B, N, bias, y, ldy);
     return (int)hipGetLastError();
 }
 

@@ -448,7 +448,7 @@ class UNetEngine:
             prev = self.a[l]
         # information vector branch (dl_models/u_net.py:253-263) + Add (:229)
         ops.embedding_fwd(self.emb_idx, p["vec.embedding"], self.emb_out)
-        ops.conv2d_fwd(self.geo["vec.dense"], self.flat, p["vec.dense.kernel"], p["vec.dense.bias"], self.v)
+        ops.dense_fwd(self.flat, p["vec.dense.kernel"], p["vec.dense.bias"], self.v, self.ws)
         self.dropout_mask = dropout_mask
         if dropout_mask is not None:
             ops.mul(self.v.base, dropout_mask, self.vd.base)
@@ -572,7 +572,7 @@ class UNetEngine:
             ops.conv2d_wgrad(self.geo["vec.dense"], self.flat, gv, g["vec.dense.kernel"], ws_)
         with self._wg() as ws_:
             ops.colsum(gv, g["vec.dense.bias"], ws_)
-        ops.conv2d_dgrad(self.geo["vec.dense"], gv, pt["vec.dense.kernel"], self.g_flat)
+        ops.dense_fwd(gv, pt["vec.dense.kernel"], None, self.g_flat, self.ws)      # dL/dflat = dv . W (the [in][out] copy)
         with self._wg() as ws_:
             ops.embedding_bwd(self.emb_idx, self.g_emb_out, g["vec.embedding"])
         ready("vec.embedding")

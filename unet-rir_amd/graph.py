@@ -92,8 +92,16 @@ class GraphEngine:
         g = ops.geom(B, x.a.H, x.a.W, cin, co, k, stride)
         reg = lambda: (2.0 * L2_COEF / self.n_replicas) if l2 else 0.0
 
+        def dense_dgrad(dst, add):
+            if add is None:      # split-K path: the weight matrix streams from every CU
+                ops.dense_fwd(y.g, self._pt[kname], None, dst, self.ws)
+            else:
+                ops.conv2d_dgrad(g, y.g, self._pt[kname], dst, addend=add)
+
         def fwd():
-            if transpose:
+            if dense:
+                ops.dense_fwd(x.a, self._p[kname], self._p[bname], y.a, self.ws)
+            elif transpose:
                 ops.conv2d_transpose_fwd(g, x.a, self._pt[kname], self._p[bname], y.a)
             else:
                 ops.conv2d_fwd(g, x.a, self._p[kname], self._p[bname], y.a)
@@ -105,7 +113,9 @@ class GraphEngine:
                 ops.conv2d_wgrad(g, x.a, y.g, self._g[kname], self.ws, reg=reg(), w=self._p[kname])
             if not followed_by_bn:        # a bias in front of BatchNorm has an identically zero gradient
                 ops.colsum(y.g, self._g[bname], self.ws)
-            if transpose:
+            if dense:
+                self._emit(x, dense_dgrad)
+            elif transpose:
                 self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, self._p[kname], dst, addend=add))
             else:
                 self._emit(x, lambda dst, add: ops.conv2d_dgrad(g, y.g, self._pt[kname], dst, addend=add))

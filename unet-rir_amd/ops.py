@@ -134,6 +134,14 @@ def conv2d_transpose_wgrad(g, x: Act, dy: Act, dw, ws: Workspace, reg=0.0, w=Non
           "conv2d_transpose_wgrad")
 
 
+def dense_fwd(x: Act, w, bias, y: Act, ws: Workspace):
+    """Dense on a small batch (dl_models/u_net.py:259): x [B,1,1,K] . w[N][K]^T + bias -> y [B,1,1,N]."""
+    B, K, N = x.B, x.C, y.C
+    ws.reserve(_lib.lib().unetrir_dense_fwd_ws_bytes(B, K, N))
+    check(_lib.lib().unetrir_dense_fwd_f32(_p(x), x.ld, _p(w), _p(bias), _p(y), y.ld, B, K, N, ws.ptr, ws.nbytes, _stream()),
+          "dense_fwd")
+
+
 def transpose_weight(w, wt, N, T, C_):
     """[N][T][C] -> [C][T][N]."""
     check(_lib.lib().unetrir_transpose_weight_f32(_p(w), _p(wt), N, T, C_, _stream()), "transpose_weight")
