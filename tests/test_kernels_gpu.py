@@ -53,6 +53,7 @@ CONV_CASES = [
     (3, 1, 1, 256, 64, 1, 1),      # Dense as a 1x1 conv on a 1x1 grid
     (2, 24, 70, 48, 160, 3, 1),    # patch-staged 3x3 kernel: several tiles in x / y / N, ragged edges, 2 channel chunks
     (1, 40, 64, 72, 64, 3, 1),
+    (2, 32, 72, 40, 72, 3, 2),     # stride 2, even size: the data gradient takes the fused parity-class kernel
 ]
 
 
@@ -110,7 +111,8 @@ def test_conv2d_fwd_dgrad_wgrad(U, case):
     close(dw, exp, 2e-6 * math.sqrt(B * Ho * Wo) + 1e-6, "wgrad")
 
 
-CONVT_CASES = [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (1, 5, 6, 8, 16, 6), (2, 3, 3, 128, 64, 3)]
+CONVT_CASES = [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (1, 5, 6, 8, 16, 6), (2, 3, 3, 128, 64, 3),
+               (2, 12, 40, 48, 72, 3), (1, 16, 32, 64, 64, 3)]      # the last two take the fused parity-class kernel
 
 
 @pytest.mark.parametrize("case", CONVT_CASES)
@@ -316,6 +318,7 @@ BF16_CONV_CASES = [
     (2, 16, 24, 8, 16, 3, 1), (2, 16, 24, 16, 32, 3, 2), (1, 9, 7, 8, 8, 3, 2), (2, 8, 8, 64, 128, 3, 1),
     (1, 10, 12, 40, 72, 3, 1), (1, 12, 12, 64, 8, 6, 1), (2, 16, 16, 128, 64, 3, 1), (1, 32, 32, 8, 64, 3, 1),
     (2, 24, 70, 48, 160, 3, 1), (1, 40, 64, 136, 64, 3, 1),          # patch-staged kernel: multi-tile, ragged, 3 chunks
+    (2, 32, 72, 40, 72, 3, 2),                                        # stride 2: fused parity-class data gradient
 ]
 
 
@@ -364,7 +367,8 @@ def test_conv2d_bf16(U, case):
         close(dw, (w.grad + 0.002 * w.detach()).permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * Ho * Wo) + 1e-6, "bf16 wgrad")
 
 
-@pytest.mark.parametrize("case", [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (2, 3, 3, 128, 64, 3)])
+@pytest.mark.parametrize("case", [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (2, 3, 3, 128, 64, 3), (2, 12, 40, 48, 72, 3),
+                                  (1, 16, 32, 136, 64, 3)])
 def test_conv2d_transpose_bf16(U, case):
     ops = U.ops
     B, H, W, Ci, Co, k = case

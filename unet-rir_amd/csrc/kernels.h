@@ -95,3 +95,4 @@ int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s);
 int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
                      void* ws, size_t ws_bytes, hipStream_t s);
 size_t dense_fwd_ws_bytes(int B, int K, int N);
+int launch_upconv3x3(const Conv3Args& a, int bf16, hipStream_t s);   // H, W = coarse (input) grid; output 2H x 2W
