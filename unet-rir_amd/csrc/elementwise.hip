@@ -22,14 +22,38 @@ __device__ __forceinline__ void st4(__bf16* p, float4 v) {
     *reinterpret_cast<bf16x4_t*>(p) = o;
 }
 
+// One 16-byte access per lane: 4 fp32 or 8 bf16 consecutive channels (8-byte accesses reach only ~0.6x the HBM rate).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; };
+template <> struct VecOf<__bf16> { static constexpr int N = 8; };
+__device__ __forceinline__ void ldv(const float* p, float (&o)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ldv(const __bf16* p, float (&o)[8]) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+}
+__device__ __forceinline__ void stv(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void stv(__bf16* p, const float (&o)[8]) {
+    bf16x8_t v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (__bf16)o[k];
+    *reinterpret_cast<bf16x8_t*>(p) = v;
+}
+
 namespace {
 
 struct ChanPlan { int QB, RB, ngroups, nslab; long long rows_per_slab; };
 
 // Thread layout for [P][C] per-channel reductions: QB channel-quads x RB pixel rows per block.
-inline ChanPlan chan_plan(long long P, int C) {
+inline ChanPlan chan_plan(long long P, int C, int vec = 4) {
     ChanPlan p;
-    const int CQ = C / 4;
+    const int CQ = C / vec;
     int qb = 1;
     while (qb * 2 <= CQ && qb * 2 <= 256) qb *= 2;
     p.QB = qb; p.RB = 256 / qb;
@@ -60,41 +84,44 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
                                                            const float* __restrict__ saved, int relu,
                                                            long long P, int C, int QB, long long rows_per_slab,
                                                            double* __restrict__ part) {
-    __shared__ double red[256 * 8];
+    constexpr int V = VecOf<T>::N;
+    __shared__ double red[256 * 2 * V];
     const int tid = threadIdx.x;
     const int RB = 256 / QB;
     const int ql = tid % QB, rl = tid / QB;
     const int q = blockIdx.y * QB + ql;
-    const int c0 = q * 4;
+    const int c0 = q * V;
     const bool cok = c0 < C;
     const long long p0 = (long long)blockIdx.x * rows_per_slab;
     long long p1 = p0 + rows_per_slab;
     if (p1 > P) p1 = P;
 
-    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    float sc[4] = {1, 1, 1, 1}, sh[4] = {0, 0, 0, 0}, mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1};
+    double s0[V], s1[V];
+    float sc[V], sh[V], mu[V], rs[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { s0[k] = 0; s1[k] = 0; sc[k] = 1; sh[k] = 0; mu[k] = 0; rs[k] = 1; }
     if (MODE == 2 && cok) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             sc[k] = affine[c0 + k]; sh[k] = affine[C + c0 + k];
             mu[k] = saved[c0 + k]; rs[k] = saved[C + c0 + k];
         }
     }
     if (cok) {
         for (long long p = p0 + rl; p < p1; p += RB) {
-            const float4 v = ld4(x + (size_t)p * ldx + c0);
-            const float xv[4] = {v.x, v.y, v.z, v.w};
+            float xv[V];
+            ldv(x + (size_t)p * ldx + c0, xv);
             if (MODE == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const double d = xv[k]; s0[k] += d; s1[k] += d * d; }
+                for (int k = 0; k < V; ++k) { const double d = xv[k]; s0[k] += d; s1[k] += d * d; }
             } else if (MODE == 1) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s0[k] += (double)xv[k];
+                for (int k = 0; k < V; ++k) s0[k] += (double)xv[k];
             } else {
-                const float4 gq = ld4(da + (size_t)p * ldda + c0);
-                const float gv[4] = {gq.x, gq.y, gq.z, gq.w};
+                float gv[V];
+                ldv(da + (size_t)p * ldda + c0, gv);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < V; ++k) {
                     const float a = xv[k] * sc[k] + sh[k];
                     const float g = (relu && !(a > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
                     const float xh = (xv[k] - mu[k]) * rs[k];
@@ -104,18 +131,18 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[tid * 8 + k] = s0[k]; red[tid * 8 + 4 + k] = s1[k]; }
+    for (int k = 0; k < V; ++k) { red[tid * 2 * V + k] = s0[k]; red[tid * 2 * V + V + k] = s1[k]; }
     __syncthreads();
     if (rl == 0 && cok) {
         for (int r = 1; r < RB; ++r) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s0[k] += red[(r * QB + ql) * 8 + k];
-                s1[k] += red[(r * QB + ql) * 8 + 4 + k];
+            for (int k = 0; k < V; ++k) {
+                s0[k] += red[(r * QB + ql) * 2 * V + k];
+                s1[k] += red[(r * QB + ql) * 2 * V + V + k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < V; ++k) {
             part[((size_t)blockIdx.x * C + c0 + k) * 2 + 0] = s0[k];
             part[((size_t)blockIdx.x * C + c0 + k) * 2 + 1] = s1[k];
         }
@@ -189,37 +216,37 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nsla
     coef[C + c] = (float)(ss / (double)P);
 }
 
-// y = x*scale + shift (ReLU optional), float4 over [P][C]
+// y = x*scale + shift (ReLU optional), one 16-byte vector per lane over [P][C]
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long P, int C,
                                                        const float* __restrict__ affine, int relu,
                                                        T* __restrict__ y, int ldy,
                                                        const T* __restrict__ addend = nullptr, int ldadd = 0) {
-    const int CQ = C / 4;
+    constexpr int V = VecOf<T>::N;
+    const int CQ = C / V;
     const long long total = P * CQ;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / CQ;
-        const int c0 = (int)(i - p * CQ) * 4;
-        const float4 v = ld4(x + (size_t)p * ldx + c0);
-        float4 r;
+        const int c0 = (int)(i - p * CQ) * V;
+        float r[V];
+        ldv(x + (size_t)p * ldx + c0, r);
         if (affine) {
-            const float4 sc = *reinterpret_cast<const float4*>(affine + c0);
-            const float4 sh = *reinterpret_cast<const float4*>(affine + C + c0);
-            r.x = v.x * sc.x + sh.x; r.y = v.y * sc.y + sh.y; r.z = v.z * sc.z + sh.z; r.w = v.w * sc.w + sh.w;
-        } else {
-            r = v;
+#pragma unroll
+            for (int k = 0; k < V; ++k) r[k] = r[k] * affine[c0 + k] + affine[C + c0 + k];
         }
         if (addend) {     // Add() in front of the activation (residual blocks, dl_models/res_ae.py:334, :478)
-            const float4 ad = ld4(addend + (size_t)p * ldadd + c0);
-            r.x += ad.x; r.y += ad.y; r.z += ad.z; r.w += ad.w;
+            float ad[V];
+            ldv(addend + (size_t)p * ldadd + c0, ad);
+#pragma unroll
+            for (int k = 0; k < V; ++k) r[k] += ad[k];
         }
         if (relu) {       // 1: ReLU; 2: keras LeakyReLU() (alpha = 0.3)
             const float sl = relu == 2 ? 0.3f : 0.f;
-            r.x = r.x > 0.f ? r.x : sl * r.x; r.y = r.y > 0.f ? r.y : sl * r.y;
-            r.z = r.z > 0.f ? r.z : sl * r.z; r.w = r.w > 0.f ? r.w : sl * r.w;
+#pragma unroll
+            for (int k = 0; k < V; ++k) r[k] = r[k] > 0.f ? r[k] : sl * r[k];
         }
-        st4(y + (size_t)p * ldy + c0, r);
+        stv(y + (size_t)p * ldy + c0, r);
     }
 }
 
@@ -231,20 +258,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ saved,
                                                            const float* __restrict__ coef, int relu,
                                                            T* __restrict__ dx, int lddx) {
-    const int CQ = C / 4;
+    constexpr int V = VecOf<T>::N;
+    const int CQ = C / V;
     const long long total = P * CQ;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long p = i / CQ;
-        const int c0 = (int)(i - p * CQ) * 4;
-        const float4 xv4 = ld4(x + (size_t)p * ldx + c0);
-        const float4 gv4 = ld4(da + (size_t)p * ldda + c0);
-        const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
-        const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w};
-        float out[4];
+        const int c0 = (int)(i - p * CQ) * V;
+        float xv[V], gv[V], out[V];
+        ldv(x + (size_t)p * ldx + c0, xv);
+        ldv(da + (size_t)p * ldda + c0, gv);
         if (affine) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < V; ++k) {
                 const float sc = affine[c0 + k], sh = affine[C + c0 + k];
                 const float a = xv[k] * sc + sh;
                 const float g = (relu && !(a > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
@@ -253,9 +279,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) out[k] = (relu && !(xv[k] > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
+            for (int k = 0; k < V; ++k) out[k] = (relu && !(xv[k] > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
         }
-        st4(dx + (size_t)p * lddx + c0, make_float4(out[0], out[1], out[2], out[3]));
+        stv(dx + (size_t)p * lddx + c0, out);
     }
 }
 
@@ -443,15 +469,17 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096
     if (b < 1) b = 1;
     return (unsigned)b;
 }
-static inline bool chan_ok(const void* x, int ld, long long P, int C) { return x && P > 0 && C > 0 && (C & 3) == 0 && ld >= C && (ld & 3) == 0; }
+static inline bool chan_ok(const void* x, int ld, long long P, int C, int vec = 4) {
+    return x && P > 0 && C > 0 && C % vec == 0 && ld >= C && ld % vec == 0 && ((uintptr_t)x & 15) == 0;
+}
 
 namespace {
 
 template <typename T>
 int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps, float momentum,
                   float* moving_mean, float* moving_var, float* affine, float* saved, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!chan_ok(x, ldx, P, C) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
-    const ChanPlan pl = chan_plan(P, C);
+    if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
@@ -461,32 +489,32 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
 
 template <typename T>
 int bn_apply_impl(const T* x, int ldx, long long P, int C, const float* affine, int relu, T* y, int ldy, hipStream_t s) {
-    if (!chan_ok(x, ldx, P, C) || !y || ldy < C || (ldy & 3)) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, x, ldx, P, C, affine, relu, y, ldy);
+    if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !y || ldy < C || ldy % VecOf<T>::N) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, x, ldx, P, C, affine, relu, y, ldy);
     return (int)hipGetLastError();
 }
 
 template <typename T>
 int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, const float* affine, const float* saved,
                 int relu, T* dx, int lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3) || !affine || !saved || !ws ||
+    if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !chan_ok(da, ldda, P, C, VecOf<T>::N) || !dx || lddx < C || lddx % VecOf<T>::N || !affine || !saved || !ws ||
         ws_bytes < unetrir_bn_ws_bytes(P, C))
         return UNETRIR_EINVAL;
-    const ChanPlan pl = chan_plan(P, C);
+    const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
     hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, relu, dx, lddx);
     return (int)hipGetLastError();
 }
 
 template <typename T>
 int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!chan_ok(x, ldx, P, C) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
-    const ChanPlan pl = chan_plan(P, C);
+    if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out);
@@ -495,8 +523,8 @@ int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, s
 
 template <typename T>
 int relu_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, T* dx, int lddx, hipStream_t s) {
-    if (!chan_ok(x, ldx, P, C) || !chan_ok(da, ldda, P, C) || !dx || lddx < C || (lddx & 3)) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, da, ldda, x, ldx, P, C,
+    if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !chan_ok(da, ldda, P, C, VecOf<T>::N) || !dx || lddx < C || lddx % VecOf<T>::N) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, da, ldda, x, ldx, P, C,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1, dx, lddx);
     return (int)hipGetLastError();
 }
