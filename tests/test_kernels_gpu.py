@@ -319,6 +319,8 @@ BF16_CONV_CASES = [
     (1, 10, 12, 40, 72, 3, 1), (1, 12, 12, 64, 8, 6, 1), (2, 16, 16, 128, 64, 3, 1), (1, 32, 32, 8, 64, 3, 1),
     (2, 24, 70, 48, 160, 3, 1), (1, 40, 64, 136, 64, 3, 1),          # patch-staged kernel: multi-tile, ragged, 3 chunks
     (2, 32, 72, 40, 72, 3, 2),                                        # stride 2: fused parity-class data gradient
+    (2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1),            # LDS-DMA kernel (conv3x3g): ragged tiles / channels, 3 chunks
+    (2, 32, 32, 128, 256, 3, 1),                                      # LDS-DMA kernel: forward 4 chunks, data gradient 8 chunks
 ]
 
 

@@ -11,6 +11,7 @@
 // [Cin][T][Cout] weight copy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -258,5 +259,10 @@ static int launch_conv3x3_t(const Conv3Args& a, hipStream_t s) {
 }
 
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
+    // bf16: the row-reuse kernel (conv3x3r.hip) unless UNETRIR_CONV3X3R=0 or a timing experiment asks for the no-store variant
+    static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
+    static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
+    if (bf16 && dma && conv3x3g_applies(a)) return launch_conv3x3g_bf16(a, s);
+    if (bf16 && rowreuse && !(a.flip & 2)) return launch_conv3x3r_bf16(a, s);
     return bf16 ? launch_conv3x3_t<__bf16>(a, s) : launch_conv3x3_t<float>(a, s);
 }

@@ -1,0 +1,271 @@
+// conv3x3g.hip - bf16 3x3 stride-1 'same' convolution (forward / data gradient): LDS-DMA staged, loads in flight across
+// barriers, patch rows reused from registers.
+//
+// Why a third 3x3 kernel: conv3x3.hip (register-staged, one barrier per tap, 16 MFMAs per wave between barriers) tops out
+// near 0.9 PFLOP/s - the known ceiling of "stage -> vmcnt(0) -> barrier -> compute" loops on this chip.  This kernel keeps
+// the staging loads in flight across the barriers instead:
+//   * a workgroup is 8 waves (2 per SIMD, one workgroup per CU) and owns 16 image rows x 32 columns x 128 output channels;
+//     a wave owns 4 rows x 32 columns x 64 channels (128 accumulator registers);
+//   * K advances in chunks of 32 input channels.  The (16+2) x 34 pixel patch of a chunk is staged once (two buffers), the
+//     [3 vertical taps][128 channels][32 input channels] weight tile of one horizontal tap dx per step (ring of three);
+//   * everything is staged with global_load_lds_dwordx4 (no staging VGPRs, no ds_write); the LDS images are lane-linear and
+//     the 16-byte granules of a 64-byte row are XOR-swizzled on the SOURCE address and again on the fragment read;
+//     out-of-image pixels read a zero page;
+//   * one raw s_barrier per step, preceded by a COUNTED s_waitcnt vmcnt(N): the weight tile of step s+2 and the patch of
+//     the next chunk stay in flight while step s computes.  Fragment reads are inline-asm ds_read_b128, so the compiler
+//     does not drain the DMA queue in front of them (it waits vmcnt(0) before any LDS load it can see while an LDS-DMA
+//     is outstanding);
+//   * for a fixed dx a patch-row fragment feeds the three vertical taps and a weight fragment feeds four output rows:
+//     12 fragment reads per 24 v_mfma_f32_32x32x16_bf16.
+// Requires C % 32 == 0 (the launcher falls back to conv3x3.hip otherwise).  The data gradient is the same kernel with
+// flipped taps on the [Cin][9][Cout] weight copy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __attribute__((aligned(256))) const uint32_t conv3x3g_zero_page[64] = {0};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+#define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define MMA(accv, wfrag, pfrag) \
+    accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), accv, 0, 0, 0)
+
+namespace {
+constexpr int GPC = 34;                    // patch columns
+constexpr int GTR = 16;                    // tile rows
+constexpr int GNPX = (GTR + 2) * GPC;      // 612 patch pixels
+constexpr int GP_INSTR = (GNPX + 15) / 16; // 39 wave-instructions of 16 pixels x 64 B
+constexpr int GP_BYTES = GP_INSTR * 1024;  // 39936
+constexpr int GBN = 128;
+constexpr int GW_BYTES = 3 * GBN * 64;     // 24576 = 24 wave-instructions
+constexpr int GP_PER_WAVE = 5;             // ceil(39 / 8)
+constexpr int GW_PER_WAVE = 3;             // 24 / 8
+constexpr int GSROW = 64 * 2 + 16;
+constexpr int GSMEM = 2 * GP_BYTES + 3 * GW_BYTES;   // 153600
+}  // namespace
+
+__global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GSMEM];
+    const __bf16* __restrict__ in = (const __bf16*)a.in;
+    const __bf16* __restrict__ w = (const __bf16*)a.w;
+    const __bf16* zp = (const __bf16*)conv3x3g_zero_page;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + GTR - 1) / GTR;
+    const int ntN = (a.N + GBN - 1) / GBN;
+    int id = blockIdx.x;
+    if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);   // neighbouring tiles on one XCD (shared L2)
+    const int nt = id % ntN; id /= ntN;
+    const int tx = id % tiles_x; id /= tiles_x;
+    const int ty = id % tiles_y;
+    const int img = id / tiles_y;
+    const int y0 = ty * GTR, x0 = tx * 32, n0 = nt * GBN;
+    const int C = a.C;
+    const int nch = C / 32;
+    const int ldw = 9 * C;
+
+    // ---- per-lane DMA sources (chunk / step invariant part)
+    const int slot = lane & 3, sub = lane >> 2;
+    const __bf16* pa[GP_PER_WAVE];
+    int pi[GP_PER_WAVE];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < GP_PER_WAVE; ++j) {
+        int i = wave + 8 * j;
+        if (i > GP_INSTR - 1) i = GP_INSTR - 1;          // wave 7's fifth instruction repeats the last one (uniform DMA counts)
+        pi[j] = i;
+        const int p = 16 * i + sub;
+        const int pr = p / GPC, pc = p - pr * GPC;
+        const int gs = slot ^ ((pc >> 2) & 3);
+        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+        const bool ok = p < GNPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        pa[j] = in + ((size_t)((long long)img * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.ldi + gs * 8;
+        pok |= (ok ? 1u : 0u) << j;
+    }
+    const __bf16* wp[GW_PER_WAVE];
+    unsigned wok = 0;
+    const int dxs = (a.flip & 1) ? -C : C;              // weight-tap step per dx
+#pragma unroll
+    for (int j = 0; j < GW_PER_WAVE; ++j) {
+        const int row = 16 * (wave + 8 * j) + sub;     // dy * 128 + local channel
+        const int dy = row >> 7, nl = row & 127;
+        const int gs = slot ^ ((nl >> 2) & 3);
+        const int n = n0 + nl;
+        const bool ok = n < a.N;
+        const int tap0 = (a.flip & 1) ? 8 - 3 * dy : 3 * dy;
+        wp[j] = w + (size_t)(ok ? n : 0) * ldw + tap0 * C + gs * 8;
+        wok |= (ok ? 1u : 0u) << j;
+    }
+    auto issue_p = [&](int ch) {
+        unsigned char* dst = smem + (ch & 1) * GP_BYTES;
+        const int c0 = ch * 32;
+#pragma unroll
+        for (int j = 0; j < GP_PER_WAVE; ++j) glds16(((pok >> j) & 1) ? pa[j] + c0 : zp, dst + pi[j] * 1024);
+    };
+    auto issue_w = [&](int ch, int dx, int buf) {
+        unsigned char* dst = smem + 2 * GP_BYTES + buf * GW_BYTES;
+        const int off = ch * 32 + dx * dxs;
+#pragma unroll
+        for (int j = 0; j < GW_PER_WAVE; ++j) glds16(((wok >> j) & 1) ? wp[j] + off : zp, dst + (wave + 8 * j) * 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: patch 0, weight steps 0 and 1
+    issue_p(0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    // fragment addresses: weights  row (dy*128 + wn*64 + j*32 + l31) * 64 + ((kk*2+hi)*16 ^ swz(l31))
+    //                     patch    ((4*wm + r) * 34 + l31 + dx) * 64 + ((kk*2+hi)*16 ^ swz(l31 + dx))
+    const uint32_t b_lane = lds0 + 2 * GP_BYTES + (wn * 64 + l31) * 64;
+    const uint32_t b_swz = (l31 & 12) << 2;
+    const uint32_t a_lane = lds0 + (4 * wm * GPC + l31) * 64;
+
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = ch + 1 < nch;
+        const uint32_t a_chunk = a_lane + (ch & 1) * GP_BYTES;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            // ---- prefetch: weight tile of step s+2 (ring slot (dx+2)%3), patch of the next chunk
+            if (dx == 0) {
+                issue_w(ch, 2, 2);
+                if (more) issue_p(ch + 1);
+            } else if (more) {
+                issue_w(ch + 1, dx - 1, dx - 1);
+            }
+            const uint32_t a_dx = a_chunk + dx * 64;
+            const uint32_t a_swz = ((l31 + dx) & 12) << 2;
+            const uint32_t b_buf = b_lane + dx * GW_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint32_t g16 = (kk * 2 + hi) << 4;
+                const uint32_t ba = b_buf + (g16 ^ b_swz);
+                const uint32_t aa = a_dx + (g16 ^ a_swz);
+                u32x4 w00, w01, w10, w11, w20, w21, p0, p1, p2, p3, p4, p5;
+                DSR128(w00, ba, 0 * 8192 + 0);
+                DSR128(w01, ba, 0 * 8192 + 2048);
+                DSR128(p0, aa, 0 * 2176);
+                DSR128(w10, ba, 1 * 8192 + 0);
+                DSR128(w11, ba, 1 * 8192 + 2048);
+                DSR128(p1, aa, 1 * 2176);
+                DSR128(w20, ba, 2 * 8192 + 0);
+                DSR128(w21, ba, 2 * 8192 + 2048);
+                DSR128(p2, aa, 2 * 2176);
+                DSR128(p3, aa, 3 * 2176);
+                DSR128(p4, aa, 4 * 2176);
+                DSR128(p5, aa, 5 * 2176);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                // patch row r feeds output row r - dy through vertical tap dy
+                MMA(acc[0][0], w00, p0); MMA(acc[0][1], w01, p0);
+                MMA(acc[1][0], w00, p1); MMA(acc[1][1], w01, p1);
+                MMA(acc[0][0], w10, p1); MMA(acc[0][1], w11, p1);
+                MMA(acc[2][0], w00, p2); MMA(acc[2][1], w01, p2);
+                MMA(acc[1][0], w10, p2); MMA(acc[1][1], w11, p2);
+                MMA(acc[0][0], w20, p2); MMA(acc[0][1], w21, p2);
+                MMA(acc[3][0], w00, p3); MMA(acc[3][1], w01, p3);
+                MMA(acc[2][0], w10, p3); MMA(acc[2][1], w11, p3);
+                MMA(acc[1][0], w20, p3); MMA(acc[1][1], w21, p3);
+                MMA(acc[3][0], w10, p4); MMA(acc[3][1], w11, p4);
+                MMA(acc[2][0], w20, p4); MMA(acc[2][1], w21, p4);
+                MMA(acc[3][0], w20, p5); MMA(acc[3][1], w21, p5);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- retire what the next step reads; younger DMAs stay in flight across the barrier
+            if (dx == 0) {
+                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W(s+2) + P(ch+1) may remain
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");        // W(s+2) may remain
+            } else if (dx == 1) {
+                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // P(ch+1) + W(s+2) may remain
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // W(s+2) may remain; P(ch+1) is older: retired
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+
+    // ---- epilogue through LDS (all DMAs retired, every wave past the last barrier), two image rows of the wave at a time:
+    // acc[i][j] holds D[n = 32j + (r&3) + 8(r>>2) + 4*hi][pixel column = l31] of image row y0 + 4*wm + i.
+    unsigned char* stage = smem + wave * (64 * GSROW);
+    const int cq = lane & 7, pl = lane >> 3;
+    const int nq = n0 + wn * 64 + cq * 8;
+    __bf16* __restrict__ out = (__bf16*)a.out;
+    const __bf16* __restrict__ addend = (const __bf16*)a.addend;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = 32 * j + 8 * qd + 4 * hi;
+                const int n = n0 + wn * 64 + nl;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias && n + 3 < a.N) bv = *reinterpret_cast<const float4*>(a.bias + n);
+                else if (a.bias) { float* bp = &bv.x; for (int e = 0; e < 4; ++e) if (n + e < a.N) bp[e] = a.bias[n + e]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x16& c = acc[2 * half + i][j];
+                    bf16x4 o;
+                    o[0] = (__bf16)(c[4 * qd + 0] + bv.x); o[1] = (__bf16)(c[4 * qd + 1] + bv.y);
+                    o[2] = (__bf16)(c[4 * qd + 2] + bv.z); o[3] = (__bf16)(c[4 * qd + 3] + bv.w);
+                    *reinterpret_cast<bf16x4*>(stage + (32 * i + l31) * GSROW + nl * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int p = ps * 8 + pl;
+            const int y = y0 + 4 * wm + 2 * half + (p >> 5), x = x0 + (p & 31);
+            if (y >= a.H || x >= a.W || nq >= a.N) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(stage + p * GSROW + cq * 16);
+            const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+            if (addend) {
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addend + pix * a.ldadd + nq);
+                bf16x8 vv = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = (__bf16)((float)vv[e] + (float)ad[e]);
+                v = __builtin_bit_cast(uint4, vv);
+            }
+            *reinterpret_cast<uint4*>(out + pix * a.ldo + nq) = v;
+        }
+    }
+}
+
+// true when the LDS-DMA kernel takes this layer (bf16, C a multiple of 32, more than 64 output channels)
+bool conv3x3g_applies(const Conv3Args& a) { return a.C % 32 == 0 && a.N > 64 && !(a.flip & 2); }
+
+int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
+    const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);
+    hipLaunchKernelGGL(conv3x3g_bf16_kernel, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    return (int)hipGetLastError();
+}

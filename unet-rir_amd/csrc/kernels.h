@@ -92,6 +92,9 @@ struct Conv3Args {
     int flip;                 // 0: forward (weight tap t at offset t); 1: data gradient (weight tap 8-t at offset t)
 };
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s);
+int launch_conv3x3r_bf16(const Conv3Args& a, hipStream_t s);
+bool conv3x3g_applies(const Conv3Args& a);
+int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
                      void* ws, size_t ws_bytes, hipStream_t s);
 size_t dense_fwd_ws_bytes(int B, int K, int N);
