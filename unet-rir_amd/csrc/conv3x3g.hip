@@ -8,9 +8,9 @@
 //     a wave owns 4 rows x 32 columns x 64 channels (128 accumulator registers);
 //   * K advances in chunks of 32 input channels.  The (16+2) x 34 pixel patch of a chunk is staged once (two buffers), the
 //     [3 vertical taps][128 channels][32 input channels] weight tile of one horizontal tap dx per step (ring of three);
-//   * everything is staged with global_load_lds_dwordx4 (no staging VGPRs, no ds_write); the LDS images are lane-linear and
+//   * everything is staged with buffer_load_dwordx4 ... lds (no staging VGPRs, no ds_write); the LDS images are lane-linear and
 //     the 16-byte granules of a 64-byte row are XOR-swizzled on the SOURCE address and again on the fragment read;
-//     out-of-image pixels read a zero page;
+//     out-of-image pixels carry a buffer offset past num_records and read zeros;
 //   * one raw s_barrier per step, preceded by a COUNTED s_waitcnt vmcnt(N): the weight tile of step s+2 and the patch of
 //     the next chunk stay in flight while step s computes.  Fragment reads are inline-asm ds_read_b128, so the compiler
 //     does not drain the DMA queue in front of them (it waits vmcnt(0) before any LDS load it can see while an LDS-DMA
@@ -21,21 +21,21 @@
 // flipped taps on the [Cin][9][Cout] weight copy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __attribute__((aligned(256))) const uint32_t conv3x3g_zero_page[64] = {0};
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
 #define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MMA16(accv, wfrag, pfrag) \
+    accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), accv, 0, 0, 0)
 #define MMA(accv, wfrag, pfrag) \
     accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), accv, 0, 0, 0)
 
@@ -53,15 +53,17 @@ constexpr int GSROW = 64 * 2 + 16;
 constexpr int GSMEM = 2 * GP_BYTES + 3 * GW_BYTES;   // 153600
 }  // namespace
 
+template <int VAR>
 __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[GSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const __bf16* __restrict__ w = (const __bf16*)a.w;
-    const __bf16* zp = (const __bf16*)conv3x3g_zero_page;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr bool S16 = (VAR & 2) != 0;              // v_mfma_f32_16x16x32_bf16 body
 
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + GTR - 1) / GTR;
     const int ntN = (a.N + GBN - 1) / GBN;
@@ -76,11 +78,15 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     const int nch = C / 32;
     const int ldw = 9 * C;
 
-    // ---- per-lane DMA sources (chunk / step invariant part)
+    // ---- per-lane DMA sources (chunk / step invariant part): byte offsets into two raw buffers (this image / the weights);
+    // invalid lanes (halo outside the image, channels >= N) carry an offset past num_records and read zeros
+    constexpr uint32_t OOB = 0xF0000000u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(in + (size_t)img * a.H * a.W * a.ldi), (short)0, (int)((((size_t)a.H * a.W - 1) * a.ldi + C) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w, (short)0, (int)((size_t)a.N * ldw * 2), 0x00020000);
     const int slot = lane & 3, sub = lane >> 2;
-    const __bf16* pa[GP_PER_WAVE];
+    uint32_t pa[GP_PER_WAVE];
     int pi[GP_PER_WAVE];
-    unsigned pok = 0;
 #pragma unroll
     for (int j = 0; j < GP_PER_WAVE; ++j) {
         int i = wave + 8 * j;
@@ -88,46 +94,54 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
         pi[j] = i;
         const int p = 16 * i + sub;
         const int pr = p / GPC, pc = p - pr * GPC;
-        const int gs = slot ^ ((pc >> 2) & 3);
+        const int gs = S16 ? slot ^ ((pc & 4) >> 1) : slot ^ ((pc >> 2) & 3);
         const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
         const bool ok = p < GNPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        pa[j] = in + ((size_t)((long long)img * a.H + (ok ? iy : 0)) * a.W + (ok ? ix : 0)) * a.ldi + gs * 8;
-        pok |= (ok ? 1u : 0u) << j;
+        pa[j] = ok ? (uint32_t)(((iy * a.W + ix) * a.ldi + gs * 8) * 2) : OOB;
     }
-    const __bf16* wp[GW_PER_WAVE];
-    unsigned wok = 0;
-    const int dxs = (a.flip & 1) ? -C : C;              // weight-tap step per dx
+    uint32_t wp[GW_PER_WAVE];
+    const int dxs = ((a.flip & 1) ? -C : C) * 2;        // weight-tap step per dx, bytes
 #pragma unroll
     for (int j = 0; j < GW_PER_WAVE; ++j) {
         const int row = 16 * (wave + 8 * j) + sub;     // dy * 128 + local channel
         const int dy = row >> 7, nl = row & 127;
-        const int gs = slot ^ ((nl >> 2) & 3);
+        const int gs = S16 ? slot ^ ((nl & 4) >> 1) : slot ^ ((nl >> 2) & 3);
         const int n = n0 + nl;
-        const bool ok = n < a.N;
         const int tap0 = (a.flip & 1) ? 8 - 3 * dy : 3 * dy;
-        wp[j] = w + (size_t)(ok ? n : 0) * ldw + tap0 * C + gs * 8;
-        wok |= (ok ? 1u : 0u) << j;
+        wp[j] = n < a.N ? (uint32_t)((n * ldw + tap0 * C + gs * 8) * 2) : OOB;
     }
     auto issue_p = [&](int ch) {
         unsigned char* dst = smem + (ch & 1) * GP_BYTES;
-        const int c0 = ch * 32;
+        const uint32_t c0b = ch * 64;
 #pragma unroll
-        for (int j = 0; j < GP_PER_WAVE; ++j) glds16(((pok >> j) & 1) ? pa[j] + c0 : zp, dst + pi[j] * 1024);
+        for (int j = 0; j < GP_PER_WAVE; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(dst + pi[j] * 1024), 16, pa[j] + c0b, 0, 0, 0);
     };
     auto issue_w = [&](int ch, int dx, int buf) {
         unsigned char* dst = smem + 2 * GP_BYTES + buf * GW_BYTES;
-        const int off = ch * 32 + dx * dxs;
+        const uint32_t off = ch * 64 + dx * dxs;
 #pragma unroll
-        for (int j = 0; j < GW_PER_WAVE; ++j) glds16(((wok >> j) & 1) ? wp[j] + off : zp, dst + (wave + 8 * j) * 1024);
+        for (int j = 0; j < GW_PER_WAVE; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + (wave + 8 * j) * 1024), 16, wp[j] + off, 0, 0, 0);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[S16 ? 1 : 4][S16 ? 1 : 2];             // 32x32x16 body: [image row][32-channel tile]
+    f32x4 acc16[S16 ? 4 : 1][2][4];                   // 16x16x32 body: [image row][16-pixel half][16-channel tile]
+    if constexpr (S16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int t = 0; t < 4; ++t) acc16[i][h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int i = 0; i < (S16 ? 1 : 4); ++i)
+#pragma unroll
+            for (int j = 0; j < (S16 ? 1 : 2); ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     // ---- prologue: patch 0, weight steps 0 and 1
     issue_p(0);
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     for (int ch = 0; ch < nch; ++ch) {
         const bool more = ch + 1 < nch;
         const uint32_t a_chunk = a_lane + (ch & 1) * GP_BYTES;
-#pragma unroll
+#pragma unroll 1
         for (int dx = 0; dx < 3; ++dx) {
             // ---- prefetch: weight tile of step s+2 (ring slot (dx+2)%3), patch of the next chunk
             if (dx == 0) {
@@ -159,6 +173,38 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             const uint32_t a_dx = a_chunk + dx * 64;
             const uint32_t a_swz = ((l31 + dx) & 12) << 2;
             const uint32_t b_buf = b_lane + dx * GW_BYTES;
+            const uint32_t b_buf16 = lds0 + 2 * GP_BYTES + dx * GW_BYTES + (wn * 64 + l15) * 64;
+            if constexpr (S16) {
+                // one pass over the 32-channel chunk: lane (l15, lq) reads granule lq of row l15 (weights: channel, patch: pixel)
+                const uint32_t ba = b_buf16 + ((lq << 4) ^ ((l15 & 4) << 3));
+                const uint32_t aa = lds0 + (ch & 1) * GP_BYTES + (4 * wm * GPC + l15 + dx) * 64 + ((lq << 4) ^ (((l15 + dx) & 4) << 3));
+                u32x4 wf[3][4], pf[6][2];
+#define RDW(dy) DSR128(wf[dy][0], ba, dy * 8192 + 0); DSR128(wf[dy][1], ba, dy * 8192 + 1024); \
+                DSR128(wf[dy][2], ba, dy * 8192 + 2048); DSR128(wf[dy][3], ba, dy * 8192 + 3072)
+#define RDP(r) DSR128(pf[r][0], aa, r * 2176 + 0); DSR128(pf[r][1], aa, r * 2176 + 1024)
+#define ROWS16(r)                                                                              \
+    _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) {                                         \
+        if (r - dy < 0 || r - dy > 3) continue;                                                \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) MMA16(acc16[r - dy][h][t], wf[dy][t], pf[r][h]); \
+    }
+                RDW(0); RDP(0); RDW(1); RDP(1); RDW(2); RDP(2);          // 18 reads in flight
+                __builtin_amdgcn_s_setprio(1);
+                LGKM_WAIT(12); ROWS16(0);
+                RDP(3);
+                LGKM_WAIT(8); ROWS16(1);
+                RDP(4);
+                LGKM_WAIT(4); ROWS16(2);
+                RDP(5);
+                LGKM_WAIT(4); ROWS16(3);
+                LGKM_WAIT(2); ROWS16(4);
+                LGKM_WAIT(0); ROWS16(5);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+#undef RDW
+#undef RDP
+#undef ROWS16
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const uint32_t g16 = (kk * 2 + hi) << 4;
@@ -177,24 +223,29 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
                 DSR128(p3, aa, 3 * 2176);
                 DSR128(p4, aa, 4 * 2176);
                 DSR128(p5, aa, 5 * 2176);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
+                // counted waits: the reads return in issue order, each MFMA group starts as soon as its fragments are in
                 __builtin_amdgcn_s_setprio(1);
-                // patch row r feeds output row r - dy through vertical tap dy
+                if constexpr (VAR & 1) LGKM_WAIT(9); else if constexpr (9 == 9) LGKM_WAIT(0);
                 MMA(acc[0][0], w00, p0); MMA(acc[0][1], w01, p0);
+                if constexpr (VAR & 1) LGKM_WAIT(6); else if constexpr (6 == 9) LGKM_WAIT(0);
                 MMA(acc[1][0], w00, p1); MMA(acc[1][1], w01, p1);
                 MMA(acc[0][0], w10, p1); MMA(acc[0][1], w11, p1);
+                if constexpr (VAR & 1) LGKM_WAIT(3); else if constexpr (3 == 9) LGKM_WAIT(0);
                 MMA(acc[2][0], w00, p2); MMA(acc[2][1], w01, p2);
                 MMA(acc[1][0], w10, p2); MMA(acc[1][1], w11, p2);
                 MMA(acc[0][0], w20, p2); MMA(acc[0][1], w21, p2);
+                if constexpr (VAR & 1) LGKM_WAIT(2); else if constexpr (2 == 9) LGKM_WAIT(0);
                 MMA(acc[3][0], w00, p3); MMA(acc[3][1], w01, p3);
                 MMA(acc[2][0], w10, p3); MMA(acc[2][1], w11, p3);
                 MMA(acc[1][0], w20, p3); MMA(acc[1][1], w21, p3);
+                if constexpr (VAR & 1) LGKM_WAIT(1); else if constexpr (1 == 9) LGKM_WAIT(0);
                 MMA(acc[3][0], w10, p4); MMA(acc[3][1], w11, p4);
                 MMA(acc[2][0], w20, p4); MMA(acc[2][1], w21, p4);
+                LGKM_WAIT(0);
                 MMA(acc[3][0], w20, p5); MMA(acc[3][1], w21, p5);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             // ---- retire what the next step reads; younger DMAs stay in flight across the barrier
             if (dx == 0) {
@@ -222,6 +273,27 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
+        if constexpr (S16) {
+            // acc16[i][h][t][e] = D[n = 16t + 4*lq + e][pixel column = 16h + l15] of image row y0 + 4*wm + i
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int nl = 16 * t + 4 * lq;
+                const int n = n0 + wn * 64 + nl;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias && n + 3 < a.N) bv = *reinterpret_cast<const float4*>(a.bias + n);
+                else if (a.bias) { float* bp = &bv.x; for (int e = 0; e < 4; ++e) if (n + e < a.N) bp[e] = a.bias[n + e]; }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4& c = acc16[S16 ? 2 * half + i : 0][h][t];
+                        bf16x4 o;
+                        o[0] = (__bf16)(c[0] + bv.x); o[1] = (__bf16)(c[1] + bv.y);
+                        o[2] = (__bf16)(c[2] + bv.z); o[3] = (__bf16)(c[3] + bv.w);
+                        *reinterpret_cast<bf16x4*>(stage + (32 * i + 16 * h + l15) * GSROW + nl * 2) = o;
+                    }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -233,7 +305,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
                 else if (a.bias) { float* bp = &bv.x; for (int e = 0; e < 4; ++e) if (n + e < a.N) bp[e] = a.bias[n + e]; }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const f32x16& c = acc[2 * half + i][j];
+                    const f32x16& c = acc[S16 ? 0 : 2 * half + i][S16 ? 0 : j];
                     bf16x4 o;
                     o[0] = (__bf16)(c[4 * qd + 0] + bv.x); o[1] = (__bf16)(c[4 * qd + 1] + bv.y);
                     o[2] = (__bf16)(c[4 * qd + 2] + bv.z); o[3] = (__bf16)(c[4 * qd + 3] + bv.w);
@@ -262,10 +334,16 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 }
 
 // true when the LDS-DMA kernel takes this layer (bf16, C a multiple of 32, more than 64 output channels)
-bool conv3x3g_applies(const Conv3Args& a) { return a.C % 32 == 0 && a.N > 64 && !(a.flip & 2); }
+bool conv3x3g_applies(const Conv3Args& a) {
+    const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2, w_bytes = (size_t)a.N * 9 * a.C * 2;
+    return a.C % 32 == 0 && a.N > 64 && !(a.flip & 2) && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
+}
 
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);
-    hipLaunchKernelGGL(conv3x3g_bf16_kernel, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    static const int var = [] { const char* e = getenv("UNETRIR_G_VAR"); return e ? atoi(e) : 1; }();
+    if (var & 2) hipLaunchKernelGGL(conv3x3g_bf16_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    else if (var & 1) hipLaunchKernelGGL(conv3x3g_bf16_kernel<1>, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(conv3x3g_bf16_kernel<0>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     return (int)hipGetLastError();
 }
