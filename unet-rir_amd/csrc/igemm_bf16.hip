@@ -8,6 +8,7 @@
 //                         through ds_read_b64_tr_b16 (hardware 4x16 transpose), two reads per operand.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -228,15 +229,19 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a)
 // ------------------------------------------------------------------------------------------------
 #define TPW 8
 
-template <int SI, int TPH>
+template <int SI, int TPH, int PADV = 1>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH a) {
     constexpr int XH = (TPH - 1) * SI + 3, XW = (TPW - 1) * SI + 3;
     constexpr int XN = XH * XW * 8;                  // 16-byte slots of the x patch (8 per pixel: 64 channels)
     constexpr int XJ = (XN + 255) / 256;
     constexpr int DN = TPH * TPW * 8;                // 16-byte slots of the dy patch
     constexpr int DJ = (DN + 255) / 256;
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[XH * XW * LDH];
-    __shared__ __attribute__((aligned(16))) __bf16 Ds[TPH * TPW * LDH];
+    // Row strides (elements) chosen for the transposed reads: a 16-lane group of ds_read_b64_tr_b16 touches 4 pixel rows x
+    // 64 B (two groups share a 32-lane conflict domain), so 4 consecutive rows - SI rows apart in the x patch - must start
+    // 64 B apart modulo the 256-B bank row: 192 B for stride-1 rows, 160 B for the stride-2 x patch (144 B is 2-way).
+    constexpr int LDD = PADV ? 96 : 72, LDX = PADV ? (SI == 1 ? 96 : 80) : 72;
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[XH * XW * LDX];
+    __shared__ __attribute__((aligned(16))) __bf16 Ds[TPH * TPW * LDD];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -299,8 +304,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH
     const int chan = (grp & 1) * 16 + tp * 4;
     // pixel (inside a 16-pixel K step = 2 patch rows of 8) supplied by this lane for read rd: row h, col 4*rd + tq
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-    const int dlane = (h * 8 + tq) * LDH + wr * 32 + chan;                       // + (s*16 + 4*rd) * LDH
-    const int xlane = ((h * SI) * XW + tq * SI) * LDH + wc * 32 + chan;          // + ((2s*SI + kh) * XW + 4*rd*SI + kw) * LDH
+    const int dlane = (h * 8 + tq) * LDD + wr * 32 + chan;                       // + (s*16 + 4*rd) * LDD
+    const int xlane = ((h * SI) * XW + tq * SI) * LDX + wc * 32 + chan;          // + ((2s*SI + kh) * XW + 4*rd*SI + kw) * LDX
 
     if (g0 < g1) load_patch(g0);
     for (int g = g0; g < g1; ++g) {
@@ -308,12 +313,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int i = tid + 256 * j;
-            if (i < XN) *reinterpret_cast<uint4*>(&Xs[(i >> 3) * LDH + q8 * 8]) = rx[j];
+            if (i < XN) *reinterpret_cast<uint4*>(&Xs[(i >> 3) * LDX + q8 * 8]) = rx[j];
         }
 #pragma unroll
         for (int j = 0; j < DJ; ++j) {
             const int i = tid + 256 * j;
-            if (i < DN) *reinterpret_cast<uint4*>(&Ds[(i >> 3) * LDH + q8 * 8]) = rd[j];
+            if (i < DN) *reinterpret_cast<uint4*>(&Ds[(i >> 3) * LDD + q8 * 8]) = rd[j];
         }
         __syncthreads();
         if (g + 1 < g1) load_patch(g + 1);
@@ -321,16 +326,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH
         for (int s = 0; s < TPH / 2; ++s) {
             bf16x8 fa;
             {
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ds + dlane + (s * 16) * LDH));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ds + dlane + (s * 16 + 4) * LDH));
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ds + dlane + (s * 16) * LDD));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Ds + dlane + (s * 16 + 4) * LDD));
                 fa = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int kh = t / 3, kw = t - kh * 3;
-                const int off0 = ((2 * s * SI + kh) * XW + kw) * LDH;
+                const int off0 = ((2 * s * SI + kh) * XW + kw) * LDX;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0 + 4 * SI * LDH));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0 + 4 * SI * LDX));
                 const bf16x8 fb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
             }
@@ -404,14 +409,21 @@ void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit
 
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
     int ns, per;
-    wgrad3x3_plan_tph(stride == 1 ? TPH_S1 : TPH_S2, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    static const int tall = [] { const char* e = getenv("UNETRIR_WG_TALL"); return e ? atoi(e) : 0; }();
+    const bool big = tall && (stride == 1 ? a.OH % 16 == 0 : a.OH % 8 == 0);
+    wgrad3x3_plan_tph(stride == 1 ? (big ? 16 : TPH_S1) : (big ? 8 : TPH_S2), a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
     const size_t nout = (size_t)a.N * 9 * a.C;
     const bool direct = (ns == 1 && reg == 0.f);
     if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return UNETRIR_EINVAL;
     a.part = direct ? dw : (float*)ws;
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
-    if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1>), dim3(tiles, ns), dim3(256), 0, s, a);
+    static const int oldpad = [] { const char* e = getenv("UNETRIR_WG_OLDPAD"); return e ? atoi(e) : 0; }();
+    if (oldpad && stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1, 0>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else if (oldpad) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_S2, 0>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else if (big && stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 16>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else if (big) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, 8>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1>), dim3(tiles, ns), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_S2>), dim3(tiles, ns), dim3(256), 0, s, a);
     int err = (int)hipGetLastError();
     if (err || direct) return err;

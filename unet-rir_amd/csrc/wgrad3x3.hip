@@ -8,6 +8,7 @@
 // Staged bytes per MFMA fall ~5x against the gathered form; partial slabs + fixed-order reduce keep it deterministic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -128,7 +129,8 @@ void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit
     *npx = (OW + TPW - 1) / TPW;
     const long long G = (long long)B * (*npy) * (*npx);
     const long long tiles = (long long)((N + 63) / 64) * ((C + 63) / 64);
-    long long want = (1024 + tiles - 1) / tiles;
+    static const long long target = [] { const char* e = getenv("UNETRIR_WG_TARGET"); return e ? atoll(e) : 512ll; }();
+    long long want = (target + tiles - 1) / tiles;
     long long maxs = (G + 3) / 4;                       // at least 4 patches per slice
     if (maxs < 1) maxs = 1;
     if (want > maxs) want = maxs;
