@@ -322,7 +322,7 @@ def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
         x = conv_block_1(x, P, f"dec{l}.cb1a", cfg, bn_state, training, inter, q, qw)
         x = feature_block(x, P, f"dec{l}", cfg, bn_state, training, inter, q, qw)
     # UpSampling2D((1,1)) is the identity; Conv2D(2,(6,6),'same') + sigmoid (:247-249)
-    x = conv2d_same(x, P["head.kernel"], P["head.bias"], 1)      # logits stay fp32 in every mode
+    x = conv2d_same(x, qw(P["head.kernel"]), P["head.bias"], 1)  # logits stay fp32 in every mode (bf16 mode: bf16 kernel copy)
     if storage == "bf16":
         x = _QuantBwd.apply(x)                                   # ... but dL/dlogits is stored in bf16
     if inter is not None:

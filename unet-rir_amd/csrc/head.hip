@@ -4,6 +4,7 @@
 // the 21x21-pixel input patch of a 16x16 output tile is staged once in LDS for all 36 taps.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 #define HT 16                 // output tile edge
@@ -154,6 +155,10 @@ template <typename T>
 int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
         return UNETRIR_EINVAL;
+    if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip) for images up to 256 pixels wide
+        static const bool mfma = [] { const char* e = getenv("UNETRIR_HEAD_MFMA"); return !(e && e[0] == '0'); }();
+        if (mfma && head_mfma_applies(W, C) && (ldx & 7) == 0) return launch_head_fwd_mfma(x, ldx, B, H, W, C, w, bias, y, ldy, s);
+    }
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
     if (C % 32 == 0) hipLaunchKernelGGL((head_fwd_kernel<32, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
     else if (C % 16 == 0) hipLaunchKernelGGL((head_fwd_kernel<16, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
@@ -167,6 +172,15 @@ int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy
     if (!x || !dy || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || lddy < 2 || (lddy & 1) ||
         ws_bytes < (size_t)HEAD_WGRAD_BLOCKS * 2 * HK * HK * C * sizeof(float))
         return UNETRIR_EINVAL;
+    if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip)
+        static const bool mfma = [] { const char* e = getenv("UNETRIR_HEAD_MFMA"); return !(e && e[0] == '0'); }();
+        if (mfma && W <= 256 && C % 64 == 0 && (ldx & 7) == 0) {
+            int nb = 0;
+            const int err = launch_head_wgrad_mfma(x, ldx, B, H, W, C, dy, lddy, (float*)ws, HEAD_WGRAD_BLOCKS, &nb, s);
+            if (err) return err;
+            return launch_splitk_reduce((const float*)ws, nb, (size_t)2 * HK * HK * C, dw, 0.f, nullptr, s);
+        }
+    }
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
     const int nblk = tiles < HEAD_WGRAD_BLOCKS ? (int)tiles : HEAD_WGRAD_BLOCKS;
     if (C % 32 == 0)

@@ -1,0 +1,262 @@
+// head_mfma.hip - bf16 fast paths of the output head Conv2D(2, (6,6), padding='same') (dl_models/u_net.py:248) on the
+// matrix cores, for images at most 256 pixels wide.
+//
+// With 2 output channels the plain implicit GEMM wastes 15/16 of every MFMA tile and the direct VALU kernels of head.hip
+// run 10x above their HBM floor.  Here the horizontal taps are folded into the MFMA's 16-wide dimension instead:
+//     S[y][q][(n,kw)] = sum_kh sum_c  w[n][kh][kw][c] * x[y + kh - 2][q][c]          (12 of 16 rows used, K = 6 * C)
+//     out[y][x][n]    = bias[n] + sum_kw S[y][x + kw - 2][(n,kw)]                     (a 6-term shifted sum through LDS)
+// so a 16-pixel x fragment feeds 6 * C/32 MFMAs instead of 36 * C/32, every input pixel is loaded from HBM once per
+// workgroup (fragment loads straight to registers, no LDS staging) and the kernel is bound by reading x.
+// A workgroup (8 waves x 32 pixels) owns up to 256 columns x R output rows of one image and walks the INPUT rows: row iy
+// contributes to the six output rows iy - kh + 2, whose accumulators live in a rotating register window (the loop is
+// unrolled by 6 so the window index is static); output row iy - 3 is complete after input row iy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define HM_ROWS 32            // output rows per workgroup
+
+template <int NCH>
+__global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int ldy) {
+    constexpr int C = 32 * NCH;
+    __shared__ __attribute__((aligned(16))) float S[2][256][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nrb = (H + HM_ROWS - 1) / HM_ROWS;
+    const int img = blockIdx.x / nrb, rb = blockIdx.x - img * nrb;
+    const int y0 = rb * HM_ROWS;
+    const int nrows = (H - y0) < HM_ROWS ? (H - y0) : HM_ROWS;
+
+    // weight fragments (A operand): row = (n,kw) index l15 (12 used), k = 8 channels lq*8.. of chunk ch, per vertical tap kh
+    bf16x8 wf[6][NCH];
+#pragma unroll
+    for (int kh = 0; kh < 6; ++kh)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            if (l15 < 12) {
+                const int n = l15 / 6, kw = l15 - n * 6;
+                const float* src = w + ((size_t)(n * 36 + kh * 6 + kw)) * C + ch * 32 + lq * 8;
+                const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+                v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+            }
+            wf[kh][ch] = v;
+        }
+
+    // x fragments (B operand): column = pixel q, k = 8 channels; two 16-pixel tiles per wave
+    const int q0 = wave * 32 + l15;
+    const __bf16* xb = x + (size_t)img * H * W * ldx + lq * 8;
+    auto load_row = [&](int iy, bf16x8 (&f)[2][NCH]) {
+        const bool rok = (unsigned)iy < (unsigned)H;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = q0 + 16 * t;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+                if (rok && q < W) v = *reinterpret_cast<const bf16x8*>(xb + ((size_t)iy * W + q) * ldx + ch * 32);
+                f[t][ch] = v;
+            }
+        }
+    };
+
+    f32x4 acc[6][2];
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float b0 = bias ? bias[0] : 0.f, b1 = bias ? bias[1] : 0.f;
+    bf16x8 xa[2][NCH], xn[2][NCH];
+    load_row(y0 - 2, xa);
+    const int nsteps = nrows + 5;                     // input rows y0-2 .. y0+nrows+2
+    // one step: input row i (relative to y0-2) -> window slots (U - kh) mod 6; output row i-5 leaves from slot (U+1) mod 6
+#define HM_STEP(U, CUR, NXT)                                                                                     \
+    if (i + U < nsteps) {                                                                                        \
+        const int ii = i + U;                                                                                    \
+        load_row(y0 - 2 + ii + 1, NXT);                                                                          \
+        if ((unsigned)(y0 - 2 + ii) < (unsigned)H) {                                                             \
+            _Pragma("unroll") for (int kh = 0; kh < 6; ++kh) {                                                   \
+                const int orow = ii - kh;                                                                        \
+                if (orow < 0 || orow >= nrows) continue;                                                         \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                    \
+                    _Pragma("unroll") for (int ch = 0; ch < NCH; ++ch)                                           \
+                        acc[(U + 6 - kh) % 6][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kh][ch], CUR[t][ch], acc[(U + 6 - kh) % 6][t], 0, 0, 0); \
+            }                                                                                                    \
+        }                                                                                                        \
+        const int orow = ii - 5;                                                                                 \
+        if (orow >= 0) {                                                                                         \
+            float(*Sb)[16] = S[ii & 1];                                                                          \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                      \
+                *reinterpret_cast<f32x4*>(&Sb[wave * 32 + 16 * t + l15][4 * lq]) = acc[(U + 1) % 6][t];          \
+                acc[(U + 1) % 6][t] = f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
+            }                                                                                                    \
+            __syncthreads();                                                                                     \
+            if (tid < W) {                                                                                       \
+                float o0 = b0, o1 = b1;                                                                          \
+                _Pragma("unroll") for (int kw = 0; kw < 6; ++kw) {                                               \
+                    const int q = tid + kw - 2;                                                                  \
+                    if ((unsigned)q < 256u) { o0 += Sb[q][kw]; o1 += Sb[q][6 + kw]; }                            \
+                }                                                                                                \
+                const size_t p = ((size_t)img * H + y0 + orow) * W + tid;                                        \
+                if (ldy >= 4) *reinterpret_cast<float4*>(y + p * ldy) = make_float4(o0, o1, 0.f, 0.f);           \
+                else { y[p * ldy] = o0; y[p * ldy + 1] = o1; }                                                   \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    for (int i = 0; i < nsteps; i += 6) {
+        HM_STEP(0, xa, xn)
+        HM_STEP(1, xn, xa)
+        HM_STEP(2, xa, xn)
+        HM_STEP(3, xn, xa)
+        HM_STEP(4, xa, xn)
+        HM_STEP(5, xn, xa)
+    }
+#undef HM_STEP
+}
+
+bool head_mfma_applies(int W, int C) { return W <= 256 && (C == 32 || C == 64 || C == 128); }
+
+int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy,
+                         hipStream_t s) {
+    const unsigned grid = (unsigned)(B * ((H + HM_ROWS - 1) / HM_ROWS));
+    const __bf16* xp = (const __bf16*)x;
+    if (C == 32) hipLaunchKernelGGL((head_fwd_mfma_kernel<1>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy);
+    else if (C == 64) hipLaunchKernelGGL((head_fwd_mfma_kernel<2>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy);
+    else hipLaunchKernelGGL((head_fwd_mfma_kernel<4>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][kh][kw][c] = sum_{y,q} D'[y][(n,kw)][q] * x[y + kh - 2][q][c],   D'[y][(n,kw)][q] = dy[y][q - kw + 2][n]
+// One MFMA tile is [16 (n,kw) rows (12 used)] x [16 channels], K = 32 pixels of one image row.  A workgroup (4 waves, one
+// 16-channel tile each, 64 channels per blockIdx.y) walks the INPUT rows of a 32-row block: each staged x row (LDS,
+// 160-byte pixel stride so ds_read_b64_tr_b16 is conflict-free) meets the six dy rows y = iy - kh + 2, kept as shifted
+// copies D' in a 6-slot LDS ring (528-byte (n,kw) stride: conflict-free ds_read_b64).  K order inside a 32-pixel step:
+// k = 8*lq + j  <->  pixel 4*lq + j (j < 4) or 16 + 4*lq + j - 4, the same on both operands.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_h;
+
+#define HW_XL 80              // x row stride in LDS, elements (160 B)
+#define HW_DL 264             // D' (n,kw) stride, elements (528 B)
+
+__global__ __launch_bounds__(256) void head_wgrad_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W, int C,
+                                                              const __bf16* __restrict__ dy, int lddy,
+                                                              float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[2][256 * HW_XL];      // 81920 B
+    __shared__ __attribute__((aligned(16))) __bf16 Dp[6][16 * HW_DL];       // 50688 B
+    __shared__ __attribute__((aligned(16))) __bf16 dyrow[2][272];           // dy row, planar, 3 zero pixels left / 13 right
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int c0 = blockIdx.y * 64;
+    const int nrb = (H + HM_ROWS - 1) / HM_ROWS;
+
+    for (int i = tid; i < 6 * 16 * HW_DL; i += 256) (&Dp[0][0])[i] = (__bf16)0.f;   // rows 12..15 and the pads stay zero
+    for (int i = tid; i < 2 * 272; i += 256) (&dyrow[0][0])[i] = (__bf16)0.f;
+
+    f32x4 acc[6];
+#pragma unroll
+    for (int kh = 0; kh < 6; ++kh) acc[kh] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g8 = tid & 7, qsub = tid >> 3;          // x staging: 16-byte granule g8 of pixel qsub + 32*j
+    uint4 rx[8];
+    for (int blk = blockIdx.x; blk < B * nrb; blk += gridDim.x) {
+        const int img = blk / nrb, rb = blk - img * nrb;
+        const int y0 = rb * HM_ROWS;
+        const int nrows = (H - y0) < HM_ROWS ? (H - y0) : HM_ROWS;
+        const __bf16* xi = x + (size_t)img * H * W * ldx + c0 + g8 * 8;
+        const __bf16* di = dy + (size_t)img * H * W * lddy;
+        auto load_x = [&](int iy) {
+            const bool rok = (unsigned)iy < (unsigned)H;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = qsub + 32 * j;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (rok && q < W) v = *reinterpret_cast<const uint4*>(xi + ((size_t)iy * W + q) * ldx);
+                rx[j] = v;
+            }
+        };
+        load_x(y0 - 2);
+        const int nsteps = nrows + 5;
+        for (int i = 0; i < nsteps; ++i) {
+            const int iy = y0 - 2 + i;
+            __syncthreads();                          // previous step's MFMAs are done with Xs[(i+1)&1]'s twin and with the ring
+            __bf16* Xb = Xs[i & 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(Xb + (qsub + 32 * j) * HW_XL + g8 * 8) = rx[j];
+            const bool newdy = i < nrows;             // dy row y0 + i enters the ring (vertical tap kh = 0 of this x row)
+            if (newdy) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
+                if (tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)(y0 + i) * W + tid) * lddy);
+                dyrow[0][tid + 3] = d[0]; dyrow[1][tid + 3] = d[1];
+            }
+            __syncthreads();
+            if (newdy) {
+                __bf16* Db = Dp[(y0 + i) % 6];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int kw = 0; kw < 6; ++kw) Db[(n * 6 + kw) * HW_DL + tid] = dyrow[n][tid - kw + 2 + 3];
+            }
+            if (i + 1 < nsteps) load_x(iy + 1);
+            __syncthreads();
+            if ((unsigned)iy < (unsigned)H) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    // B operand (x, transposed read): group lq supplies pixel rows ks*32 + 4*lq + r (+16), channels wave*16 + 4p..
+                    const int r = l15 >> 2, p = l15 & 3;
+                    const __bf16* xr = Xb + (ks * 32 + 4 * lq + r) * HW_XL + wave * 16 + 4 * p;
+                    const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)xr);
+                    const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(xr + 16 * HW_XL));
+                    const bf16x8 fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int kh = 0; kh < 6; ++kh) {
+                        const int orow = i - kh;      // dy row y0 + orow
+                        if (orow < 0 || orow >= nrows) continue;
+                        const __bf16* dr = Dp[(y0 + orow) % 6] + l15 * HW_DL + ks * 32 + 4 * lq;
+                        const bf16x4 alo = *reinterpret_cast<const bf16x4*>(dr);
+                        const bf16x4 ahi = *reinterpret_cast<const bf16x4*>(dr + 16);
+                        const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[kh], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // acc[kh][j] = dW[(n,kw) = 4*lq + j][kh][channel c0 + wave*16 + l15]
+    float* out = part + (size_t)blockIdx.x * 2 * 36 * C;
+    const int c = c0 + wave * 16 + l15;
+#pragma unroll
+    for (int kh = 0; kh < 6; ++kh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = 4 * lq + j;
+            if (idx < 12) {
+                const int n = idx / 6, kw = idx - n * 6;
+                out[(size_t)(n * 36 + kh * 6 + kw) * C + c] = acc[kh][j];
+            }
+        }
+}
+
+int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
+                           int* nblk_out, hipStream_t s) {
+    int nblk = B * ((H + HM_ROWS - 1) / HM_ROWS);
+    if (nblk > max_blocks) nblk = max_blocks;
+    *nblk_out = nblk;
+    hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nblk, C / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
+                       (const __bf16*)dy, lddy, part);
+    return (int)hipGetLastError();
+}
