@@ -238,6 +238,13 @@ int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W
                              const float* bias, float* y, int ldy, unetrir_stream_t stream);
 int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy,
                                int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* head data gradient on the matrix cores: dx[p][c] = sum_{n<2,kh,kw} dy[p - off][n] * w[n][kh][kw][c] (the adjoint of
+ * unetrir_head6x6_fwd_bf16; w is the fp32 [>=2][6][6][C] kernel, rounded to bf16 on load).  Only channels 0,1 of dy are
+ * read.  Supported for W <= 256 and C == 64 (unetrir_head6x6_dgrad_supported); otherwise UNETRIR_EINVAL and the caller
+ * uses unetrir_conv2d_dgrad_bf16 on the padded kernel. */
+int unetrir_head6x6_dgrad_supported(int W, int C);
+int unetrir_head6x6_dgrad_bf16(const unetrir_bf16* dy, int lddy, int B, int H, int W, const float* w, int C,
+                               unetrir_bf16* dx, int lddx, unetrir_stream_t stream);
 /* as unetrir_sigmoid_loss_f32 / unetrir_sigmoid_bwd_f32 but dlogits is bf16 [B*H*W][8] (channels 2..7 zero) */
 int unetrir_sigmoid_loss_bf16(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha,
                               float inv_norm, float* pred, unetrir_bf16* dlogits, float* loss_out, void* ws,

@@ -472,6 +472,15 @@ def test_head_and_loss_bf16(U, B, H, W, Cc):
     ops.head6x6_wgrad(xa, dl, dw, ws)
     torch.cuda.synchronize()
     close(dw[:2], w2.grad.permute(3, 0, 1, 2), 2e-6 * math.sqrt(B * H * W) + 1e-6, "head wgrad (bf16 in)")
+    # data gradient (matrix-core kernel where supported) from the same bf16 dlogits
+    if ops.head6x6_dgrad_supported(W, Cc):
+        x2 = x.clone().requires_grad_(True)
+        (R.conv2d_same(x2, w.detach(), b, 1) * gl).sum().backward()
+        dxa = ops.Act(torch.full((B, H, W, Cc + 8), 3.0, dtype=torch.bfloat16, device=DEV), 8, Cc)
+        ops.head6x6_dgrad(dl, w8, dxa)
+        torch.cuda.synchronize()
+        close(dxa.dense().permute(0, 3, 1, 2), x2.grad, 1e-2, "head dgrad (bf16)")
+        assert float(dxa.base[..., :8].float().min()) == 3.0 and float(dxa.base[..., :8].float().max()) == 3.0
 
 
 @pytest.mark.parametrize("B,K,N", [(32, 8192, 4096), (3, 520, 72), (4, 4096, 8192)])

@@ -107,6 +107,9 @@ _SIGS = {
                                            C.c_int, c_stream]),
     "unetrir_head6x6_wgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                              c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_head6x6_dgrad_supported": (C.c_int, [C.c_int, C.c_int]),
+    "unetrir_head6x6_dgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
+                                             c_stream]),
     "unetrir_sigmoid_loss_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                             c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_sigmoid_bwd_bf16": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),

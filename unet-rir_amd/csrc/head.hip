@@ -222,4 +222,14 @@ int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int
     return head_wgrad_impl<__bf16>((const __bf16*)x, ldx, B, H, W, C, (const __bf16*)dy, lddy, dw, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int unetrir_head6x6_dgrad_supported(int W, int C) { return head_dgrad_mfma_applies(W, C) ? 1 : 0; }
+
+int unetrir_head6x6_dgrad_bf16(const unetrir_bf16* dy, int lddy, int B, int H, int W, const float* w, int C, unetrir_bf16* dx, int lddx,
+                               unetrir_stream_t stream) {
+    if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || !head_dgrad_mfma_applies(W, C) || lddy < 2 || (lddy & 1) || lddx < C ||
+        (lddx & 7) || ((uintptr_t)dx & 15) || ((uintptr_t)dy & 3))
+        return UNETRIR_EINVAL;
+    return launch_head_dgrad_mfma(dy, lddy, B, H, W, w, dx, lddx, (hipStream_t)stream);
+}
+
 }  // extern "C"

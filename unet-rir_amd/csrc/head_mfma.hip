@@ -260,3 +260,123 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
                        (const __bf16*)dy, lddy, part);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// data gradient:  dx[y][q][c] = sum_kh sum_(n,kw) Dq[y - kh + 2][q][(n,kw)] * w[n][kh][kw][c],   Dq[r][q][(n,kw)] = dy[r][q - kw + 2][n]
+// One MFMA tile is [16 channels] x [16 pixels], K = 32 = two vertical taps x 16 (n,kw) slots (12 used); three K steps
+// cover the six vertical taps.  The weight fragments (12) stay in registers; the dy rows are expanded once into their
+// 32-byte-per-pixel (n,kw) images in a 6-slot LDS ring, read conflict-free by ds_read_b128.  A workgroup (4 waves x 64
+// pixels, C = 64) walks 32 output rows; results leave through an LDS row image as 16-byte NHWC stores (the kernel is
+// bound by writing dx).
+// ------------------------------------------------------------------------------------------------------------------
+#define HD_OL 72              // output row image: pixel stride in elements (144 B)
+
+__global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __restrict__ dy, int lddy, int B, int H, int W,
+                                                              const float* __restrict__ w, __bf16* __restrict__ dx, int lddx) {
+    constexpr int C = 64;
+    __shared__ __attribute__((aligned(16))) __bf16 Dq[6][256 * 16];        // 49152 B
+    __shared__ __attribute__((aligned(16))) __bf16 Os[256 * HD_OL];        // 36864 B
+    __shared__ __attribute__((aligned(16))) __bf16 dyrow[2][272];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nrb = (H + HM_ROWS - 1) / HM_ROWS;
+    const int img = blockIdx.x / nrb, rb = blockIdx.x - img * nrb;
+    const int y0 = rb * HM_ROWS;
+    const int nrows = (H - y0) < HM_ROWS ? (H - y0) : HM_ROWS;
+    const __bf16* di = dy + (size_t)img * H * W * lddy;
+
+    for (int i = tid; i < 2 * 272; i += 256) (&dyrow[0][0])[i] = (__bf16)0.f;
+
+    // weight fragments (A operand): row = channel ct*16 + l15, k = 8*lq + j <-> vertical tap 2*kp + (lq>>1), slot 8*(lq&1) + j
+    bf16x8 wf[3][4];
+#pragma unroll
+    for (int kp = 0; kp < 3; ++kp)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            bf16x8 v;
+            const int kh = 2 * kp + (lq >> 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = 8 * (lq & 1) + j;
+                float f = 0.f;
+                if (idx < 12) {
+                    const int n = idx / 6, kw = idx - n * 6;
+                    f = w[(size_t)(n * 36 + kh * 6 + kw) * C + ct * 16 + l15];
+                }
+                v[j] = (__bf16)f;
+            }
+            wf[kp][ct] = v;
+        }
+
+    // expand dy row r into ring slot r mod 6 (all threads; two barriers inside)
+    auto push_row = [&](int r) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
+        if ((unsigned)r < (unsigned)H && tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)r * W + tid) * lddy);
+        __syncthreads();
+        dyrow[0][tid + 3] = d[0]; dyrow[1][tid + 3] = d[1];
+        __syncthreads();
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i0 = e, i1 = 8 + e;             // (n,kw) slots 0..7 and 8..15
+            lo[e] = dyrow[i0 / 6][tid - (i0 % 6) + 5];
+            hi[e] = i1 < 12 ? dyrow[i1 / 6][tid - (i1 % 6) + 5] : (__bf16)0.f;
+        }
+        __bf16* dst = Dq[((r % 6) + 6) % 6] + tid * 16;
+        *reinterpret_cast<bf16x8*>(dst) = lo;
+        *reinterpret_cast<bf16x8*>(dst + 8) = hi;
+    };
+    for (int r = y0 - 3; r < y0 + 2; ++r) push_row(r);
+
+    for (int yy = 0; yy < nrows; ++yy) {
+        const int yo = y0 + yy;
+        push_row(yo + 2);                             // the slot it replaces (row yo - 4) was last read one step ago, two barriers back
+        __syncthreads();
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[t][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < 3; ++kp) {
+            const int r = yo - (2 * kp + (lq >> 1)) + 2;     // dy row of this lane's vertical tap
+            const __bf16* src = Dq[((r % 6) + 6) % 6] + (wave * 64 + l15) * 16 + 8 * (lq & 1);
+            const bool rok = (unsigned)r < (unsigned)H;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bf16x8 fb = *reinterpret_cast<const bf16x8*>(src + t * 256);
+                if (!rok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fb[e] = (__bf16)0.f;
+                }
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kp][ct], fb, acc[t][ct], 0, 0, 0);
+            }
+        }
+        // acc[t][ct][j] = dx[yo][q = wave*64 + 16t + l15][c = ct*16 + 4*lq + j]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                bf16x4 o;
+                o[0] = (__bf16)acc[t][ct][0]; o[1] = (__bf16)acc[t][ct][1]; o[2] = (__bf16)acc[t][ct][2]; o[3] = (__bf16)acc[t][ct][3];
+                *reinterpret_cast<bf16x4*>(Os + (wave * 64 + 16 * t + l15) * HD_OL + ct * 16 + 4 * lq) = o;
+            }
+        __syncthreads();
+        __bf16* orow = dx + ((size_t)img * H + yo) * W * lddx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = (tid >> 3) + 32 * j, g = tid & 7;
+            if (q < W) *reinterpret_cast<uint4*>(orow + (size_t)q * lddx + g * 8) = *reinterpret_cast<const uint4*>(Os + q * HD_OL + g * 8);
+        }
+    }
+}
+
+bool head_dgrad_mfma_applies(int W, int C) { return W <= 256 && C == 64; }
+
+int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s) {
+    const unsigned grid = (unsigned)(B * ((H + HM_ROWS - 1) / HM_ROWS));
+    hipLaunchKernelGGL(head_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, s, (const __bf16*)dy, lddy, B, H, W, w, (__bf16*)dx, lddx);
+    return (int)hipGetLastError();
+}

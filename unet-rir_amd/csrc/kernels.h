@@ -97,6 +97,8 @@ bool head_mfma_applies(int W, int C);
 int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s);
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
                            int* nblk_out, hipStream_t s);
+bool head_dgrad_mfma_applies(int W, int C);
+int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s);
 bool conv3x3g_applies(const Conv3Args& a);
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,

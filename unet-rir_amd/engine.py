@@ -520,7 +520,10 @@ class UNetEngine:
         ready("head.bias")
         top = self.ab[1] if D >= 1 else self.a[1]
         g_cur = self.g_ab[1] if D >= 1 else self.g_z
-        ops.conv2d_dgrad(self.geo["head"], gl, self.wb("head.kernel"), g_cur)
+        if self.head_direct and self.dtype == "bf16" and ops.head6x6_dgrad_supported(self.W, self.ch[0]):
+            ops.head6x6_dgrad(gl, self.p["head.kernel"], g_cur)
+        else:
+            ops.conv2d_dgrad(self.geo["head"], gl, self.wb("head.kernel"), g_cur)
         for l in range(1, D + 1):
             c = self.ch[l - 1]
             # cb1b

@@ -255,6 +255,18 @@ def head6x6_wgrad(x: Act, dy: Act, dw, ws: Workspace):
                                                _stream()), "head6x6_wgrad")
 
 
+def head6x6_dgrad_supported(W_, C_):
+    return bool(_lib.lib().unetrir_head6x6_dgrad_supported(W_, C_))
+
+
+def head6x6_dgrad(dy: Act, w, dx: Act):
+    """Adjoint of head6x6_fwd on bf16 activations (matrix-core kernel): dx = conv-transpose of dy[..., :2] with the fp32 kernel w."""
+    if dy.sfx != "bf16" or dx.sfx != "bf16":
+        raise ValueError("head6x6_dgrad is a bf16-storage kernel")
+    check(_lib.lib().unetrir_head6x6_dgrad_bf16(_p(dy), dy.ld, dy.B, dy.H, dy.W, _p(w), dx.C, _p(dx), dx.ld, _stream()),
+          "head6x6_dgrad")
+
+
 def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_out, ws: Workspace):
     """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits."""
     B, _, H, W = target.shape
