@@ -341,7 +341,7 @@ bool conv3x3g_applies(const Conv3Args& a) {
 
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);
-    static const int var = [] { const char* e = getenv("UNETRIR_G_VAR"); return e ? atoi(e) : 1; }();
+    static const int var = [] { const char* e = getenv("UNETRIR_G_VAR"); return e ? atoi(e) : 2; }();
     if (var & 2) hipLaunchKernelGGL(conv3x3g_bf16_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     else if (var & 1) hipLaunchKernelGGL(conv3x3g_bf16_kernel<1>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(conv3x3g_bf16_kernel<0>, dim3((unsigned)tiles), dim3(512), 0, s, a);
