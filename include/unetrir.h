@@ -238,6 +238,25 @@ int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W
                              const float* bias, float* y, int ldy, unetrir_stream_t stream);
 int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy,
                                int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* ---- fused column statistics (bf16).  The 3x3 stride-1 kernels that serve most layers can emit, per 16 x 32 pixel tile,
+ *      the per-channel (sum, sum of squares) of the bf16 output they store: colstat is [rows][N][2] floats with N the
+ *      convolution's output channels (forward: Cout, data gradient: Cin).  BatchNormalization statistics (dl_models/
+ *      u_net.py:204-206) and bias gradients then come from these rows instead of re-reading the tensor.
+ *      unetrir_conv2d_colstat_rows_bf16 returns 0 when the kernel serving this layer (geometry, dgrad flag, pixel stride
+ *      ld_in of its input) has no fused statistics; the *_colstat entry points then return UNETRIR_EINVAL. */
+long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in);
+int unetrir_conv2d_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
+                                    const float* bias, const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy,
+                                    float* colstat, unetrir_stream_t stream);
+int unetrir_conv2d_dgrad_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
+                                      const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, float* colstat,
+                                      unetrir_stream_t stream);
+/* as unetrir_bn_stats_f32 / unetrir_colsum_f32 but from colstat rows; fixed-order fp64 reduction over the rows.
+ * colsum: out[0..C) = sum over rows of colstat[row][c0 + c][0], ldc = channels per row. */
+int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, int C, const float* gamma, const float* beta,
+                             float eps, float momentum, float* moving_mean, float* moving_var, float* affine, float* saved,
+                             unetrir_stream_t stream);
+int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream);
 /* head data gradient on the matrix cores: dx[p][c] = sum_{n<2,kh,kw} dy[p - off][n] * w[n][kh][kw][c] (the adjoint of
  * unetrir_head6x6_fwd_bf16; w is the fp32 [>=2][6][6][C] kernel, rounded to bf16 on load).  Only channels 0,1 of dy are
  * read.  Supported for W <= 256 and C == 64 (unetrir_head6x6_dgrad_supported); otherwise UNETRIR_EINVAL and the caller

@@ -496,3 +496,55 @@ def test_dense_split_k(U, B, K, N):
     ops.dense_fwd(xa, w.to(DEV), b.to(DEV), ya, ws)
     torch.cuda.synchronize()
     close(ya.base.view(B, N), x.double() @ w.double().t() + b.double(), 2e-6 * math.sqrt(K) + 1e-6, "dense fwd")
+
+
+@pytest.mark.parametrize("case", [(2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1), (2, 30, 64, 32, 64, 3, 1), (1, 16, 32, 16, 24, 3, 1)])
+def test_conv_fused_column_statistics_bf16(U, case):
+    """Conv epilogue statistics (conv3x3g / conv3x3r<4,1>): the per-tile (sum, sum of squares) rows must add up to the
+    statistics of the bf16 tensor the same launch stored, forward and data gradient, and BN statistics / bias gradients
+    derived from them must match the stand-alone kernels."""
+    ops = U.ops
+    B, H, W, Ci, Co, k, s = case
+    x, w, b = conv_data(case)
+    g = ops.geom(B, H, W, Ci, Co, k, s)
+    xa = ops.Act(to_nhwc_bf16(q16(x), Ci, 0, DEV))
+    wf = torch.empty((Co, 9, Ci), dtype=torch.bfloat16, device=DEV)
+    w32 = w.permute(3, 0, 1, 2).reshape(Co, 9, Ci).float().contiguous().to(DEV)
+    ops.cast_weight_bf16(w32, wf, Co, 9, Ci, Ci)
+    rows = ops.conv2d_colstat_rows(g, 0, xa)
+    assert rows == B * ((H + 15) // 16) * ((W + 31) // 32)
+    ya = ops.Act(torch.zeros((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
+    cst = torch.full((rows, Co, 2), 7.0, device=DEV)
+    ops.conv2d_fwd_colstat(g, xa, wf, b.float().to(DEV), ya, cst)
+    yref = ops.Act(torch.zeros((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
+    ops.conv2d_fwd(g, xa, wf, b.float().to(DEV), yref)
+    torch.cuda.synchronize()
+    assert torch.equal(ya.base, yref.base)
+    yd = ya.base.double()
+    tot = cst.double().sum(dim=0)
+    close(tot[:, 0], yd.sum(dim=(0, 1, 2)), 2e-6, "colstat sum")
+    close(tot[:, 1], (yd * yd).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares")
+    # BN statistics from the rows == the stand-alone kernel
+    gamma = torch.rand(Co, device=DEV) + 0.5
+    beta = torch.rand(Co, device=DEV) - 0.5
+    aff1, sav1 = torch.zeros(2 * Co, device=DEV), torch.zeros(2 * Co, device=DEV)
+    aff2, sav2 = torch.zeros(2 * Co, device=DEV), torch.zeros(2 * Co, device=DEV)
+    ws = ops.Workspace(DEV)
+    ops.bn_stats(ya, gamma, beta, aff1, sav1, ws)
+    ops.bn_stats_colstat(cst, rows, ya.P, Co, gamma, beta, aff2, sav2)
+    torch.cuda.synchronize()
+    close(aff2, aff1, 1e-5, "bn affine from colstat")
+    close(sav2, sav1, 1e-5, "bn saved from colstat")
+    # data gradient: statistics of dx, bias-gradient slice
+    rows_d = ops.conv2d_colstat_rows(g, 1, ya)
+    assert rows_d == rows
+    wt = torch.empty((Ci, 9, Co), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_cast_weight_bf16(w32, wt, Co, 9, Ci, Co)
+    dxa = ops.Act(torch.zeros((B, H, W, Ci), dtype=torch.bfloat16, device=DEV))
+    cst_d = torch.full((rows, Ci, 2), 7.0, device=DEV)
+    ops.conv2d_dgrad_colstat(g, ya, wt, dxa, cst_d)
+    c0, cn = Ci // 2, Ci - Ci // 2
+    out = torch.zeros(cn, device=DEV)
+    ops.colsum_colstat(cst_d, rows, Ci, c0, cn, out)
+    torch.cuda.synchronize()
+    close(out, dxa.base.double().sum(dim=(0, 1, 2))[c0:], 2e-6, "bias gradient from colstat")

@@ -107,6 +107,14 @@ _SIGS = {
                                            C.c_int, c_stream]),
     "unetrir_head6x6_wgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                              c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_conv2d_colstat_rows_bf16": (C.c_longlong, [C.POINTER(ConvGeom), C.c_int, C.c_int]),
+    "unetrir_conv2d_fwd_colstat_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
+                                                  c_f32p, c_stream]),
+    "unetrir_conv2d_dgrad_colstat_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
+                                                    c_f32p, c_stream]),
+    "unetrir_bn_stats_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,
+                                           c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "unetrir_colsum_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
     "unetrir_head6x6_dgrad_supported": (C.c_int, [C.c_int, C.c_int]),
     "unetrir_head6x6_dgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
                                              c_stream]),

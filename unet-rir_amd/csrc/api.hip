@@ -82,9 +82,10 @@ struct BF16 {
 // ---- Conv2D forward: iteration grid = output grid ----
 template <class P>
 int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, const typename P::T* w, const float* bias,
-                  const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s) {
+                  const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s, float* colstat = nullptr) {
     if (use_conv3x3(g->k, g->stride, g->H, g->W)) {
         Conv3Args c{};
+        c.colstat = colstat;
         c.in = x; c.ldi = ldx; c.w = w; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = y; c.ldo = ldy;
         c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout;
         static const int nostore = [] { const char* e = getenv("UNETRIR_CONV3X3_NOSTORE"); return (e && e[0] == '1') ? 2 : 0; }();
@@ -109,9 +110,10 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
 // dx[q][ci] = sum_t sum_co dy[p][co] * wt[ci][t][co]  with q = p*s + (k_t - pad_before)
 template <class P>
 int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int lddy, const typename P::T* wt, const float* bias,
-                    const typename P::T* addend, int ldadd, typename P::T* dx, int lddx, hipStream_t s) {
+                    const typename P::T* addend, int ldadd, typename P::T* dx, int lddx, hipStream_t s, float* colstat = nullptr) {
     if (use_conv3x3(g->k, g->stride, g->H, g->W)) {     // dgrad of a stride-1 3x3 conv = the same conv with flipped taps
         Conv3Args c{};
+        c.colstat = colstat;
         c.in = dy; c.ldi = lddy; c.w = wt; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = dx; c.ldo = lddx;
         c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cout; c.N = g->Cin; c.flip = 1;
         return launch_conv3x3(c, P::is_bf16, s);
@@ -307,6 +309,39 @@ int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
     return conv_dgrad_impl<BF16>(g, (const __bf16*)dy, lddy, (const __bf16*)wt, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx,
                                  lddx, (hipStream_t)stream);
+}
+
+/* Fused column statistics: the 3x3 stride-1 kernels conv3x3g / conv3x3r<4,1> can emit, per 16 x 32 pixel tile, the
+ * per-channel (sum, sum of squares) of the bf16 output they store.  rows == 0: the kernel serving this layer cannot. */
+static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) {
+    if (!geom_ok(g) || !use_conv3x3(g->k, g->stride, g->H, g->W)) return 0;
+    Conv3Args c{};
+    c.B = g->B; c.H = g->H; c.W = g->W; c.ldi = ld_in;
+    c.C = dgrad ? g->Cout : g->Cin; c.N = dgrad ? g->Cin : g->Cout; c.flip = dgrad ? 1 : 0;
+    if (!conv3x3_has_colstat(c)) return 0;
+    return (long long)g->B * ((g->H + 15) / 16) * ((g->W + 31) / 32);
+}
+long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }
+
+int unetrir_conv2d_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w, const float* bias,
+                                    const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy, float* colstat,
+                                    unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !w || !y || !colstat || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout || colstat_rows(g, 0, ldx) == 0)
+        return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
+    return conv_fwd_impl<BF16>(g, (const __bf16*)x, ldx, (const __bf16*)w, bias, (const __bf16*)addend, ldadd, (__bf16*)y, ldy,
+                               (hipStream_t)stream, colstat);
+}
+
+int unetrir_conv2d_dgrad_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
+                                      const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, float* colstat,
+                                      unetrir_stream_t stream) {
+    if (!geom_ok(g) || !dy || !wt || !dx || !colstat || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin ||
+        colstat_rows(g, 1, lddy) == 0)
+        return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
+    return conv_dgrad_impl<BF16>(g, (const __bf16*)dy, lddy, (const __bf16*)wt, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx,
+                                 lddx, (hipStream_t)stream, colstat);
 }
 
 int unetrir_conv2d_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy, int lddy,

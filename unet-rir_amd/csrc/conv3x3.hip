@@ -258,6 +258,14 @@ static int launch_conv3x3_t(const Conv3Args& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// true when launch_conv3x3(a, bf16 = 1) lands on a kernel with the fused column statistics (conv3x3g, conv3x3r<4,1>)
+bool conv3x3_has_colstat(const Conv3Args& a) {
+    static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
+    static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
+    if (dma && conv3x3g_applies(a)) return true;
+    return rowreuse && a.N <= 64 && !(a.flip & 2);
+}
+
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
     // bf16: the row-reuse kernel (conv3x3r.hip) unless UNETRIR_CONV3X3R=0 or a timing experiment asks for the no-store variant
     static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();

@@ -167,6 +167,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3r_bf16_kernel(const Conv3Args a
     const int nq = n0 + wn * 64 + cq * 8;
     __bf16* __restrict__ out = (__bf16*)a.out;
     const __bf16* __restrict__ addend = (const __bf16*)a.addend;
+    float cs_s[8], cs_q[8];                           // fused column statistics (a.colstat, <4,1> tiles only)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (half) __syncthreads();
@@ -204,7 +207,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3r_bf16_kernel(const Conv3Args a
                 for (int e = 0; e < 8; ++e) vv[e] = (__bf16)((float)vv[e] + (float)ad[e]);
                 v = __builtin_bit_cast(uint4, vv);
             }
+            if (a.colstat) {
+                const bf16x8 sv = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)sv[e]; cs_s[e] += f; cs_q[e] += f * f; }
+            }
             *reinterpret_cast<uint4*>(out + pix * a.ldo + nq) = v;
+        }
+    }
+    if constexpr (WN == 1) {
+        if (a.colstat) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) { cs_s[e] += __shfl_xor(cs_s[e], off); cs_q[e] += __shfl_xor(cs_q[e], off); }
+            }
+            float* red = reinterpret_cast<float*>(smem + 4 * 64 * SROW);   // [4 wm][64 ch][2], past the staging tiles
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(wm * 64 + lane * 8 + e) * 2 + 0] = cs_s[e];
+                    red[(wm * 64 + lane * 8 + e) * 2 + 1] = cs_q[e];
+                }
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int ch = tid >> 1, st = tid & 1;
+                const float t = ((red[(0 * 64 + ch) * 2 + st] + red[(1 * 64 + ch) * 2 + st]) + red[(2 * 64 + ch) * 2 + st]) +
+                                red[(3 * 64 + ch) * 2 + st];
+                const size_t row = ((size_t)img * tiles_y + ty) * tiles_x + tx;
+                if (n0 + ch < a.N) a.colstat[(row * a.N + n0 + ch) * 2 + st] = t;
+            }
         }
     }
 }

@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 }
 
 // Block-wide (256 threads, one block per channel) fixed-order sum of the per-slab partials of channel c.
-__device__ __forceinline__ void slab_sum(const double* __restrict__ part, int nslab, int C, int c, double& s, double& ss) {
+template <typename PT>
+__device__ __forceinline__ void slab_sum(const PT* __restrict__ part, int nslab, int C, int c, double& s, double& ss) {
     __shared__ double red[256 * 2];
     double a = 0, b = 0;
 #pragma unroll 4
-    for (int k = threadIdx.x; k < nslab; k += 256) { a += part[((size_t)k * C + c) * 2]; b += part[((size_t)k * C + c) * 2 + 1]; }
+    for (int k = threadIdx.x; k < nslab; k += 256) { a += (double)part[((size_t)k * C + c) * 2]; b += (double)part[((size_t)k * C + c) * 2 + 1]; }
     red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
     __syncthreads();
     // tree over the 256 partial sums in a fixed pairing order
@@ -169,13 +170,14 @@ __device__ __forceinline__ void slab_sum(const double* __restrict__ part, int ns
 }
 
 // stage 2 (BN statistics): mean / biased variance -> affine, saved, moving statistics
-__global__ void bn_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
+template <typename PT>
+__global__ void bn_finalize_kernel(const PT* __restrict__ part, int nslab, long long P, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                    float* __restrict__ affine, float* __restrict__ saved) {
     const int c = blockIdx.x;
     double s, ss;
-    slab_sum(part, nslab, C, c, s, ss);
+    slab_sum<PT>(part, nslab, C, c, s, ss);
     if (threadIdx.x != 0) return;
     const double mean = s / (double)P;
     double var = ss / (double)P - mean * mean;
@@ -195,10 +197,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int nslab, l
 }
 
 // stage 2 (column sum): out[c] = sum_slabs
-__global__ void colsum_finalize_kernel(const double* __restrict__ part, int nslab, int C, float* __restrict__ out) {
+template <typename PT>
+__global__ void colsum_finalize_kernel(const PT* __restrict__ part, int nslab, int C, float* __restrict__ out, int c0 = 0) {
     const int c = blockIdx.x;
     double s, ss;
-    slab_sum(part, nslab, C, c, s, ss);
+    slab_sum<PT>(part, nslab, C, c0 + c, s, ss);
     if (threadIdx.x == 0) out[c] = (float)s;
 }
 
@@ -482,7 +485,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
                        beta, eps, momentum, moving_mean, moving_var, affine, saved);
     return (int)hipGetLastError();
 }
@@ -517,7 +520,7 @@ int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, s
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out);
+    hipLaunchKernelGGL(colsum_finalize_kernel<double>, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out, 0);
     return (int)hipGetLastError();
 }
 
@@ -777,6 +780,29 @@ int unetrir_add_f32_to_bf16(const unetrir_bf16* a, const float* b, unetrir_bf16*
 int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetrir_stream_t stream) {
     if (!a || !y || n <= 0 || (n & 3)) return UNETRIR_EINVAL;
     hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, y, n / 4);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+// -------------------------------------------------------------------------------------------
+// statistics from the per-tile partials a convolution epilogue produced (unetrir_conv2d_*_colstat_bf16):
+// colstat is [rows][ldc][2] floats (sum, sum of squares); fixed-order fp64 reduction over the rows
+// -------------------------------------------------------------------------------------------
+extern "C" {
+
+int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, int C, const float* gamma, const float* beta, float eps,
+                             float momentum, float* moving_mean, float* moving_var, float* affine, float* saved,
+                             unetrir_stream_t stream) {
+    if (!colstat || rows <= 0 || rows > 0x7fffffffLL || P <= 0 || C <= 0 || !affine || !saved) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, colstat, (int)rows, P, C, gamma, beta, eps,
+                       momentum, moving_mean, moving_var, affine, saved);
+    return (int)hipGetLastError();
+}
+
+int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream) {
+    if (!colstat || rows <= 0 || rows > 0x7fffffffLL || C <= 0 || c0 < 0 || c0 + C > ldc || !out) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(colsum_finalize_kernel<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, colstat, (int)rows, ldc, out, c0);
     return (int)hipGetLastError();
 }
 

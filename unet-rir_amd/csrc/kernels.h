@@ -90,6 +90,8 @@ struct Conv3Args {
     void* out; int ldo;
     int B, H, W, C, N;
     int flip;                 // 0: forward (weight tap t at offset t); 1: data gradient (weight tap 8-t at offset t)
+    float* colstat;           // nullable; conv3x3g / conv3x3r<4,1> only: [pixel tile][N][2] per-channel (sum, sum of squares) of the
+                              // stored output, one row per 16 x 32 pixel tile (row = (img * tiles_y + ty) * tiles_x + tx)
 };
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s);
 int launch_conv3x3r_bf16(const Conv3Args& a, hipStream_t s);
@@ -100,6 +102,7 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
 bool head_dgrad_mfma_applies(int W, int C);
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s);
 bool conv3x3g_applies(const Conv3Args& a);
+bool conv3x3_has_colstat(const Conv3Args& a);
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
                      void* ws, size_t ws_bytes, hipStream_t s);

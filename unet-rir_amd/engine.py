@@ -16,6 +16,8 @@ Memory layout in HBM (all fp32):
 import math
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import ops
@@ -77,6 +79,8 @@ class UNetEngine:
             raise ValueError("dtype must be 'f32' or 'bf16'")
         # storage type of activations and their gradients; parameters, statistics and weight gradients are always fp32
         self.dtype = dtype
+        self.fused_stats = os.environ.get("UNETRIR_FUSED_STATS", "1") != "0"     # conv-epilogue BN statistics / bias gradients (bf16)
+        self._cst_rows, self._cst_buf = {}, None
         self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
         self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes
         if F0 % self.PAD:
@@ -418,6 +422,44 @@ class UNetEngine:
         else:
             ops.relu_fwd(y, out)
 
+    def _colstat(self, name, dgrad, x: Act, n_out):
+        """(rows, buffer) of fused column statistics for conv `name` (forward or data gradient), or (0, None)."""
+        key = (name, dgrad)
+        if key not in self._cst_rows:
+            self._cst_rows[key] = ops.conv2d_colstat_rows(self.geo[name], dgrad, x) if self.dtype == "bf16" and self.fused_stats else 0
+        rows = self._cst_rows[key]
+        if rows == 0:
+            return 0, None
+        need = rows * n_out * 2
+        if self._cst_buf is None or self._cst_buf.numel() < need:
+            self._cst_buf = torch.empty(need, device=self.device, dtype=torch.float32)
+        return rows, self._cst_buf
+
+    def _conv_bn_relu_fwd(self, name, x: Act, y: Act, out: Act):
+        """Conv2D -> BatchNormalization -> ReLU (conv_block_1, dl_models/u_net.py:364-371); in bf16 training the batch
+        statistics come from the convolution's own epilogue where the serving kernel provides them."""
+        p = self.p
+        rows, buf = self._colstat(name, 0, x, y.C) if (self.batchnorm and self.training) else (0, None)
+        if rows == 0:
+            ops.conv2d_fwd(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y)
+            self._bn_relu_fwd(name, y, out)
+            return
+        ops.conv2d_fwd_colstat(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y, buf)
+        ops.bn_stats_colstat(buf, rows, y.P, y.C, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name],
+                             self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
+        ops.bn_apply(y, self.bn_affine[name], out, relu=True)
+
+    def _dgrad_colsum(self, name, dy: Act, dx: Act, bias_grad, c0, c_n):
+        """Data gradient of conv `name` plus the bias gradient of the layer that produced its input (channels
+        [c0, c0+c_n) of dx summed over pixels), fused into the dgrad epilogue where the serving kernel allows."""
+        rows, buf = self._colstat(name, 1, dy, dx.C)
+        if rows == 0:
+            ops.conv2d_dgrad(self.geo[name], dy, self.wb(name + ".kernel"), dx)
+            return False
+        ops.conv2d_dgrad_colstat(self.geo[name], dy, self.wb(name + ".kernel"), dx, buf)
+        ops.colsum_colstat(buf, rows, dx.C, c0, c_n, bias_grad)
+        return True
+
     def _bn_relu_bwd(self, name, da: Act, y: Act, dy: Act):
         if self.batchnorm:
             ops.bn_bwd(da, y, self.p[name + ".gamma"], self.bn_affine[name], self.bn_saved[name], dy,
@@ -443,8 +485,7 @@ class UNetEngine:
         prev = self.x4
         for l in range(1, self.L + 1):
             ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, self.wf(f"enc{l}.down.kernel"), p[f"enc{l}.down.bias"], self.down[l])
-            ops.conv2d_fwd(self.geo[f"enc{l}.cb1"], self.down[l], self.wf(f"enc{l}.cb1.kernel"), p[f"enc{l}.cb1.bias"], self.y[l])
-            self._bn_relu_fwd(f"enc{l}.cb1", self.y[l], self.a[l])
+            self._conv_bn_relu_fwd(f"enc{l}.cb1", self.down[l], self.y[l], self.a[l])
             prev = self.a[l]
         # information vector branch (dl_models/u_net.py:253-263) + Add (:229)
         ops.embedding_fwd(self.emb_idx, p["vec.embedding"], self.emb_out)
@@ -465,10 +506,8 @@ class UNetEngine:
             c = self.ch[l - 1]
             ops.conv2d_transpose_fwd(self.geo[f"dec{l}.up"], cur, self.wb(f"dec{l}.up.kernel"), p[f"dec{l}.up.bias"],
                                      self.cat[l].slice(c, c))
-            ops.conv2d_fwd(self.geo[f"dec{l}.cb1a"], self.cat[l], self.wf(f"dec{l}.cb1a.kernel"), p[f"dec{l}.cb1a.bias"], self.ya[l])
-            self._bn_relu_fwd(f"dec{l}.cb1a", self.ya[l], self.aa[l])
-            ops.conv2d_fwd(self.geo[f"dec{l}.cb1b"], self.aa[l], self.wf(f"dec{l}.cb1b.kernel"), p[f"dec{l}.cb1b.bias"], self.yb[l])
-            self._bn_relu_fwd(f"dec{l}.cb1b", self.yb[l], self.ab[l])
+            self._conv_bn_relu_fwd(f"dec{l}.cb1a", self.cat[l], self.ya[l], self.aa[l])
+            self._conv_bn_relu_fwd(f"dec{l}.cb1b", self.aa[l], self.yb[l], self.ab[l])
             cur = self.ab[l]
         if self.head_direct:
             ops.head6x6_fwd(cur, p["head.kernel"], p["head.bias"], self.logits)
@@ -541,7 +580,7 @@ class UNetEngine:
             if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
                 with self._wg() as ws_:
                     ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws_)
-            ops.conv2d_dgrad(self.geo[f"dec{l}.cb1a"], self.g_ya[l], self.wb(f"dec{l}.cb1a.kernel"), self.g_cat[l])
+            up_bias_done = self._dgrad_colsum(f"dec{l}.cb1a", self.g_ya[l], self.g_cat[l], g[f"dec{l}.up.bias"], c, c)
             # Conv2DTranspose
             g_up = self.g_cat[l].slice(c, c)
             x_in = self.ab[l + 1] if l < D else self.z
@@ -549,8 +588,9 @@ class UNetEngine:
             with self._wg() as ws_:
                 ops.conv2d_transpose_wgrad(self.geo[f"dec{l}.up"], x_in, g_up, g[f"dec{l}.up.kernel"], ws_, reg=reg,
                                            w=p[f"dec{l}.up.kernel"])
-            with self._wg() as ws_:
-                ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
+            if not up_bias_done:
+                with self._wg() as ws_:
+                    ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
             ready(f"dec{l}.up.bias")
             ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, self.wf(f"dec{l}.up.kernel"), g_in)
         # bottleneck: z = a_L + conv1x1(dropout(dense(embedding)))
@@ -588,13 +628,14 @@ class UNetEngine:
             if not self.batchnorm:
                 with self._wg() as ws_:
                     ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws_)
-            ops.conv2d_dgrad(self.geo[f"enc{l}.cb1"], self.g_y[l], self.wb(f"enc{l}.cb1.kernel"), self.g_down[l])
+            down_bias_done = self._dgrad_colsum(f"enc{l}.cb1", self.g_y[l], self.g_down[l], g[f"enc{l}.down.bias"], 0, self.g_down[l].C)
             x_in = self.a[l - 1] if l > 1 else self.x4
             with self._wg() as ws_:
                 ops.conv2d_wgrad(self.geo[f"enc{l}.down"], x_in, self.g_down[l], g[f"enc{l}.down.kernel"], ws_, reg=reg,
                                  w=p[f"enc{l}.down.kernel"])
-            with self._wg() as ws_:
-                ops.colsum(self.g_down[l], g[f"enc{l}.down.bias"], ws_)
+            if not down_bias_done:
+                with self._wg() as ws_:
+                    ops.colsum(self.g_down[l], g[f"enc{l}.down.bias"], ws_)
             ready(f"enc{l}.down.bias")
             if l > 1:
                 skip = self.g_cat[l - 1].slice(0, self.ch[l - 2])

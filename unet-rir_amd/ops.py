@@ -101,6 +101,37 @@ def conv2d_dgrad(g, dy: Act, wt, dx: Act, addend: Act = None):
           "conv2d_dgrad")
 
 
+def conv2d_colstat_rows(g, dgrad, x: Act):
+    """Rows of fused column statistics the conv kernel serving this layer emits (0: none; bf16 storage only)."""
+    if x.sfx != "bf16":
+        return 0
+    return int(_lib.lib().unetrir_conv2d_colstat_rows_bf16(C.byref(g), int(bool(dgrad)), x.ld))
+
+
+def conv2d_fwd_colstat(g, x: Act, w, bias, y: Act, colstat, addend: Act = None):
+    """conv2d_fwd that also writes per-tile (sum, sum of squares) of the stored output: colstat [rows][Cout][2] fp32."""
+    check(_lib.lib().unetrir_conv2d_fwd_colstat_bf16(C.byref(g), _p(x), x.ld, _p(w), _p(bias), _p(addend),
+                                                     addend.ld if addend is not None else 0, _p(y), y.ld, _p(colstat), _stream()),
+          "conv2d_fwd_colstat")
+
+
+def conv2d_dgrad_colstat(g, dy: Act, wt, dx: Act, colstat, addend: Act = None):
+    check(_lib.lib().unetrir_conv2d_dgrad_colstat_bf16(C.byref(g), _p(dy), dy.ld, _p(wt), _p(addend),
+                                                       addend.ld if addend is not None else 0, _p(dx), dx.ld, _p(colstat), _stream()),
+          "conv2d_dgrad_colstat")
+
+
+def bn_stats_colstat(colstat, rows, P, C_, gamma, beta, affine, saved, moving_mean=None, moving_var=None, eps=1e-3, momentum=0.99):
+    """BatchNormalization() batch statistics from fused conv-epilogue partials."""
+    check(_lib.lib().unetrir_bn_stats_colstat(_p(colstat), rows, P, C_, _p(gamma), _p(beta), eps, momentum, _p(moving_mean),
+                                              _p(moving_var), _p(affine), _p(saved), _stream()), "bn_stats_colstat")
+
+
+def colsum_colstat(colstat, rows, ldc, c0, C_, out):
+    """Bias gradient from fused conv-epilogue partials: out[c] = sum over rows of colstat[row][c0 + c][0]."""
+    check(_lib.lib().unetrir_colsum_colstat(_p(colstat), rows, ldc, c0, C_, _p(out), _stream()), "colsum_colstat")
+
+
 def conv2d_wgrad_ws_bytes(g):
     return _lib.lib().unetrir_conv2d_wgrad_ws_bytes(C.byref(g))
 
