@@ -263,6 +263,7 @@ bool conv3x3_has_colstat(const Conv3Args& a) {
     static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
     static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
     if (dma && conv3x3g_applies(a)) return true;
+    if (conv3x3h_applies(a)) return true;
     return rowreuse && a.N <= 64 && !(a.flip & 2);
 }
 
@@ -271,6 +272,7 @@ int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
     static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
     static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
     if (bf16 && dma && conv3x3g_applies(a)) return launch_conv3x3g_bf16(a, s);
+    if (bf16 && conv3x3h_applies(a)) return launch_conv3x3h_bf16(a, s);
     if (bf16 && rowreuse && !(a.flip & 2)) return launch_conv3x3r_bf16(a, s);
     return bf16 ? launch_conv3x3_t<__bf16>(a, s) : launch_conv3x3_t<float>(a, s);
 }

@@ -408,6 +408,10 @@ void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit
 #define TPH_S2 4
 
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (stride == 1) {       // patch rows reused from registers (wgrad3x3r.hip)
+        const int err = launch_wgrad3x3r_bf16(a, dw, reg, w, ws, ws_bytes, s);
+        if (err != WGRAD3X3R_NOT_TAKEN) return err;
+    }
     int ns, per;
     static const int tall = [] { const char* e = getenv("UNETRIR_WG_TALL"); return e ? atoi(e) : 0; }();
     const bool big = tall && (stride == 1 ? a.OH % 16 == 0 : a.OH % 8 == 0);

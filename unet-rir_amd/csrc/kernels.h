@@ -78,6 +78,8 @@ struct Wgrad3ArgsH {
 };
 int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
+#define WGRAD3X3R_NOT_TAKEN (-12345)
+int launch_wgrad3x3r_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hipStream_t s);
 int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, int Np, hipStream_t s);
 
@@ -103,6 +105,8 @@ bool head_dgrad_mfma_applies(int W, int C);
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s);
 bool conv3x3g_applies(const Conv3Args& a);
 bool conv3x3_has_colstat(const Conv3Args& a);
+bool conv3x3h_applies(const Conv3Args& a);
+int launch_conv3x3h_bf16(const Conv3Args& a, hipStream_t s);
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
                      void* ws, size_t ws_bytes, hipStream_t s);
