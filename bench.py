@@ -134,8 +134,8 @@ def run_mode(U, args, dtype, world, rank, device, steps, warmup):
             "traffic_note": traffic(dtype)[1],
             "kernel": ("igemm_fwd_kernel / wgrad3x3_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv: fwd, dgrad, wgrad)"
                        if dtype == "f32" else
-                       "igemm_fwd_bf16_kernel / wgrad3x3_bf16_kernel (bf16 v_mfma_f32_32x32x16_bf16 implicit-GEMM conv: fwd, dgrad, "
-                       "wgrad)") + "; layers with Cin,Cout > 8",
+                       "conv3x3g / conv3x3h / upconv3x3 / igemm_fwd_bf16 (fwd, dgrad) + wgrad3x3r / wgrad3x3_bf16 (wgrad): bf16 "
+                       "v_mfma_f32_16x16x32_bf16 / 32x32x16 convolutions, fp32 accumulate") + "; layers with Cin,Cout > 8",
             "calls_per_step": nl / steps, "avg_call_ms": conv_ms / max(nl, 1),
             "algorithmic_gflop_per_step": conv_fl / steps / 1e9, "conv_ms_per_step": conv_ms / steps,
             "by_family": {name: {"calls": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
