@@ -219,6 +219,15 @@ int unetrir_conv2d_transpose_wgrad_bf16(const unetrir_conv_geom* g, const unetri
 int unetrir_cast_weight_bf16(const float* w, unetrir_bf16* o, int N, int T, int C, int Cp, unetrir_stream_t stream);
 int unetrir_transpose_cast_weight_bf16(const float* w, unetrir_bf16* wt, int N, int T, int C, int Np,
                                        unetrir_stream_t stream);
+/* every layer's work copies in two launches: `desc` is an array of n_layers descriptors IN DEVICE MEMORY (same
+ * semantics per layer as the two calls above; a NULL destination skips that copy). */
+typedef struct unetrir_cast_desc {
+    const float* w;            /* fp32 master [N][T][C] */
+    unetrir_bf16* same;        /* bf16 [N][T][Cp] or NULL */
+    unetrir_bf16* transposed;  /* bf16 [C][T][Np] or NULL */
+    int N, T, C, Cp, Np, reserved;
+} unetrir_cast_desc;
+int unetrir_cast_weights_batched_bf16(const unetrir_cast_desc* desc, int n_layers, unetrir_stream_t stream);
 int unetrir_bn_stats_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* gamma, const float* beta,
                           float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
                           float* saved, void* ws, size_t ws_bytes, unetrir_stream_t stream);

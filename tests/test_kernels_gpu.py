@@ -548,3 +548,27 @@ def test_conv_fused_column_statistics_bf16(U, case):
     ops.colsum_colstat(cst_d, rows, Ci, c0, cn, out)
     torch.cuda.synchronize()
     close(out, dxa.base.double().sum(dim=(0, 1, 2))[c0:], 2e-6, "bias gradient from colstat")
+
+
+def test_cast_weights_batched_bf16(U):
+    """The two-launch batched work-copy refresh equals the per-layer calls bit for bit."""
+    ops = U.ops
+    shapes = [(16, 9, 8), (72, 9, 40), (128, 1, 64), (8, 36, 64)]
+    ws, same1, tr1, same2, tr2, ent = [], [], [], [], [], []
+    for i, (N, T, Cc) in enumerate(shapes):
+        w = torch.tensor(detrand.uniform(f"cwb{i}", (N, T, Cc), -1, 1)).to(DEV)
+        ws.append(w)
+        same1.append(torch.zeros((N, T, Cc), dtype=torch.bfloat16, device=DEV)); tr1.append(torch.zeros((Cc, T, N), dtype=torch.bfloat16, device=DEV))
+        same2.append(torch.ones((N, T, Cc), dtype=torch.bfloat16, device=DEV)); tr2.append(torch.ones((Cc, T, N), dtype=torch.bfloat16, device=DEV))
+        ops.cast_weight_bf16(w, same1[-1], N, T, Cc, Cc)
+        ops.transpose_cast_weight_bf16(w, tr1[-1], N, T, Cc, N)
+        ent.append((w, same2[-1], tr2[-1] if i != 2 else None, N, T, Cc, Cc, N))
+    table = ops.make_cast_table(ent, DEV)
+    ops.cast_weights_batched(table)
+    torch.cuda.synchronize()
+    for i in range(len(shapes)):
+        assert torch.equal(same1[i], same2[i])
+        if i != 2:
+            assert torch.equal(tr1[i], tr2[i])
+        else:
+            assert float(tr2[i].float().min()) == 1.0      # NULL destination: untouched

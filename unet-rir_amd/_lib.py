@@ -13,6 +13,12 @@ c_f32p = C.c_void_p   # device pointers travel as integers
 c_stream = C.c_void_p
 
 
+class CastDesc(C.Structure):
+    """unetrir_cast_desc (include/unetrir.h)."""
+    _fields_ = [("w", C.c_void_p), ("same", C.c_void_p), ("transposed", C.c_void_p), ("N", C.c_int), ("T", C.c_int), ("C", C.c_int),
+                ("Cp", C.c_int), ("Np", C.c_int), ("reserved", C.c_int)]
+
+
 class ConvGeom(C.Structure):
     """unetrir_conv_geom"""
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
@@ -115,6 +121,7 @@ _SIGS = {
     "unetrir_bn_stats_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,
                                            c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "unetrir_colsum_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
+    "unetrir_cast_weights_batched_bf16": (C.c_int, [C.c_void_p, C.c_int, c_stream]),
     "unetrir_head6x6_dgrad_supported": (C.c_int, [C.c_int, C.c_int]),
     "unetrir_head6x6_dgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
                                              c_stream]),

@@ -397,6 +397,11 @@ int unetrir_transpose_cast_weight_bf16(const float* w, unetrir_bf16* wt, int N, 
     return launch_transpose_cast_weight(w, wt, N, T, C, Np, (hipStream_t)stream);
 }
 
+int unetrir_cast_weights_batched_bf16(const unetrir_cast_desc* desc, int n_layers, unetrir_stream_t stream) {
+    if (!desc || n_layers <= 0 || n_layers > 65535) return UNETRIR_EINVAL;
+    return launch_cast_weights_batched(desc, n_layers, (hipStream_t)stream);
+}
+
 /* Dense(N) (dl_models/u_net.py:259) on a small batch: y[B][N] = x[B][K] . w[N][K]^T + bias, split-K so that the 134 MB
  * weight matrix streams from every CU.  The data gradient is the same call with the transposed weight copy and no bias. */
 size_t unetrir_dense_fwd_ws_bytes(int B, int K, int N) { return dense_fwd_ws_bytes(B, K, N); }

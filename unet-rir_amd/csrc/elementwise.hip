@@ -390,16 +390,50 @@ __global__ void embedding_fwd_kernel(const int* __restrict__ idx, int n_idx, con
     for (int d = threadIdx.x; d < dim; d += blockDim.x) out[(size_t)i * dim + d] = table[(size_t)v * dim + d];
 }
 
-__global__ void embedding_bwd_kernel(const int* __restrict__ idx, int n_idx, const float* __restrict__ dout,
-                                     int vocab, int dim, float* __restrict__ dtable) {
+// dtable[v] = sum over the positions i (in increasing i: a fixed order) with idx[i] == v.  One block per vocabulary row:
+// the block first collects the (few) matching positions into LDS, then sums only those rows of dout.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int* __restrict__ idx, int n_idx, const float* __restrict__ dout,
+                                                            int vocab, int dim, float* __restrict__ dtable) {
+    __shared__ int list[1024];
+    __shared__ int cnt;
     const int v = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    bool overflow = false;
+    for (int i = threadIdx.x; i < n_idx; i += blockDim.x) {
+        int u = idx[i];
+        u = u < 0 ? 0 : (u >= vocab ? vocab - 1 : u);
+        if (u == v) {
+            const int k = atomicAdd(&cnt, 1);
+            if (k < 1024) list[k] = i; else overflow = true;
+        }
+    }
+    __syncthreads();
+    const int n = cnt;
+    if (n > 1024 || __syncthreads_or(overflow)) {          // pathological (one id more than 1024 times): plain ordered scan
+        for (int d = threadIdx.x; d < dim; d += blockDim.x) {
+            float s = 0.f;
+            for (int i = 0; i < n_idx; ++i) {
+                int u = idx[i];
+                u = u < 0 ? 0 : (u >= vocab ? vocab - 1 : u);
+                if (u == v) s += dout[(size_t)i * dim + d];
+            }
+            dtable[(size_t)v * dim + d] = s;
+        }
+        return;
+    }
+    if (threadIdx.x == 0 && n > 1) {                         // the list arrives in atomic order: sort it (n is tiny)
+        for (int a = 1; a < n; ++a) {
+            const int key = list[a];
+            int b = a - 1;
+            while (b >= 0 && list[b] > key) { list[b + 1] = list[b]; --b; }
+            list[b + 1] = key;
+        }
+    }
+    __syncthreads();
     for (int d = threadIdx.x; d < dim; d += blockDim.x) {
         float s = 0.f;
-        for (int i = 0; i < n_idx; ++i) {
-            int u = idx[i];
-            u = u < 0 ? 0 : (u >= vocab ? vocab - 1 : u);
-            if (u == v) s += dout[(size_t)i * dim + d];
-        }
+        for (int k = 0; k < n; ++k) s += dout[(size_t)list[k] * dim + d];
         dtable[(size_t)v * dim + d] = s;
     }
 }
@@ -437,21 +471,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, co
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
                                                    float lr_t, float b1, float b2, float eps, float gs) {
     const long long n4 = n / 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        float4 t = reinterpret_cast<float4*>(theta)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-        float* tp = &t.x; const float* gp = &gg.x; float* mp = &mm.x; float* vp = &vv.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = gp[k] * gs;
-            mp[k] = b1 * mp[k] + (1.f - b1) * gk;
-            vp[k] = b2 * vp[k] + (1.f - b2) * gk * gk;
-            tp[k] -= lr_t * mp[k] / (sqrtf(vp[k]) + eps);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    // two independent 16-byte groups per thread and iteration: 8 loads in flight before the first store
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+        const long long i2 = i + stride;
+        const bool two = i2 < n4;
+        float4 t[2], gg[2], mm[2], vv[2];
+        t[0] = reinterpret_cast<float4*>(theta)[i]; gg[0] = reinterpret_cast<const float4*>(g)[i];
+        mm[0] = reinterpret_cast<float4*>(m)[i]; vv[0] = reinterpret_cast<float4*>(v)[i];
+        if (two) {
+            t[1] = reinterpret_cast<float4*>(theta)[i2]; gg[1] = reinterpret_cast<const float4*>(g)[i2];
+            mm[1] = reinterpret_cast<float4*>(m)[i2]; vv[1] = reinterpret_cast<float4*>(v)[i2];
         }
-        reinterpret_cast<float4*>(theta)[i] = t;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            float* tp = &t[u].x; const float* gp = &gg[u].x; float* mp = &mm[u].x; float* vp = &vv[u].x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gk = gp[k] * gs;
+                mp[k] = b1 * mp[k] + (1.f - b1) * gk;
+                vp[k] = b2 * vp[k] + (1.f - b2) * gk * gk;
+                tp[k] -= lr_t * mp[k] / (sqrtf(vp[k]) + eps);
+            }
+            const long long o = u ? i2 : i;
+            reinterpret_cast<float4*>(theta)[o] = t[u];
+            reinterpret_cast<float4*>(m)[o] = mm[u];
+            reinterpret_cast<float4*>(v)[o] = vv[u];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (long long i = n4 * 4; i < n; ++i) {

@@ -383,6 +383,45 @@ __global__ void transpose_cast_weight_kernel(const float* __restrict__ w, __bf16
     }
 }
 
+// All layers of a model in two launches: desc[l] describes one fp32 master [N][T][C] and its two bf16 work copies
+// (blockIdx.y = layer).  Same element order as cast_weight_kernel / transpose_cast_weight_kernel.
+__global__ __launch_bounds__(256) void cast_weights_batched_kernel(const unetrir_cast_desc* __restrict__ desc) {
+    const unetrir_cast_desc d = desc[blockIdx.y];
+    if (!d.same) return;
+    __bf16* o = (__bf16*)d.same;
+    const size_t total = (size_t)d.N * d.T * d.Cp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % d.Cp);
+        const size_t nt = i / d.Cp;
+        o[i] = (c < d.C) ? (__bf16)d.w[nt * d.C + c] : (__bf16)0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_cast_weights_batched_kernel(const unetrir_cast_desc* __restrict__ desc) {
+    __shared__ float tile[32][33];
+    const unetrir_cast_desc d = desc[blockIdx.y];
+    if (!d.transposed) return;
+    __bf16* wt = (__bf16*)d.transposed;
+    const int ntx = (d.C + 31) / 32, nty = (d.Np + 31) / 32;
+    const int ntiles = ntx * nty * d.T;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int t = tl / (ntx * nty);
+        const int rem = tl - t * (ntx * nty);
+        const int c0 = (rem % ntx) * 32, n0 = (rem / ntx) * 32;
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int n = n0 + r, c = c0 + tx;
+            tile[r][tx] = (n < d.N && c < d.C) ? d.w[((size_t)n * d.T + t) * d.C + c] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, n = n0 + tx;
+            if (n < d.Np && c < d.C) wt[((size_t)c * d.T + t) * d.Np + n] = (__bf16)tile[tx][r];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
@@ -445,5 +484,11 @@ int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hip
 int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, int Np, hipStream_t s) {
     dim3 grid((C + 31) / 32, (Np + 31) / 32, T);
     hipLaunchKernelGGL(transpose_cast_weight_kernel, grid, dim3(256), 0, s, w, (__bf16*)wt, N, T, C, Np);
+    return (int)hipGetLastError();
+}
+
+int launch_cast_weights_batched(const unetrir_cast_desc* desc_dev, int n_layers, hipStream_t s) {
+    hipLaunchKernelGGL(cast_weights_batched_kernel, dim3(128, n_layers), dim3(256), 0, s, desc_dev);
+    hipLaunchKernelGGL(transpose_cast_weights_batched_kernel, dim3(256, n_layers), dim3(256), 0, s, desc_dev);
     return (int)hipGetLastError();
 }

@@ -81,6 +81,7 @@ int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const 
 #define WGRAD3X3R_NOT_TAKEN (-12345)
 int launch_wgrad3x3r_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hipStream_t s);
+int launch_cast_weights_batched(const unetrir_cast_desc* desc_dev, int n_layers, hipStream_t s);
 int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, int Np, hipStream_t s);
 
 // 3x3 stride-1 conv / data gradient with the halo patch staged once in LDS (conv3x3.hip); T = float or __bf16

@@ -81,6 +81,7 @@ class UNetEngine:
         self.dtype = dtype
         self.fused_stats = os.environ.get("UNETRIR_FUSED_STATS", "1") != "0"     # conv-epilogue BN statistics / bias gradients (bf16)
         self._cst_rows, self._cst_buf = {}, None
+        self._cast_table = None
         self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
         self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes
         if F0 % self.PAD:
@@ -391,11 +392,15 @@ class UNetEngine:
             if self.dtype == "bf16" and n in self.ph:
                 continue                                    # trunk kernels: bf16 copies below
             ops.transpose_weight(self.p[n], self.pt[n], N, T, C_)
-        for n in self.ph:
-            s_ = self.specs[n]
-            N, T, C_ = s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3]
-            ops.cast_weight_bf16(self.p[n], self.ph[n], N, T, C_, C_)
-            ops.transpose_cast_weight_bf16(self.p[n], self.pth[n], N, T, C_, N)
+        if self.ph:
+            if self._cast_table is None:
+                ent = []
+                for n in self.ph:
+                    s_ = self.specs[n]
+                    N, T, C_ = s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3]
+                    ent.append((self.p[n], self.ph[n], self.pth[n], N, T, C_, C_, N))
+                self._cast_table = ops.make_cast_table(ent, self.device)
+            ops.cast_weights_batched(self._cast_table)
         self.t_dirty = False
 
     def wf(self, name):

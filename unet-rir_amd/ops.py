@@ -189,6 +189,23 @@ def transpose_cast_weight_bf16(w, wt, N, T, C_, Np):
           "transpose_cast_weight_bf16")
 
 
+def make_cast_table(entries, device):
+    """Device-resident unetrir_cast_desc array for cast_weights_batched: entries = [(w fp32 [N][T][C], same bf16 or None,
+    transposed bf16 or None, N, T, C, Cp, Np)].  The returned tensor keeps the table alive; the weight tensors must too."""
+    arr = (_lib.CastDesc * len(entries))()
+    for i, (w, same, tr, N, T, C_, Cp, Np) in enumerate(entries):
+        arr[i] = _lib.CastDesc(w.data_ptr(), same.data_ptr() if same is not None else None,
+                               tr.data_ptr() if tr is not None else None, N, T, C_, Cp, Np, 0)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return raw.to(device), len(entries)
+
+
+def cast_weights_batched(table):
+    """fp32 master kernels -> bf16 work copies (both orientations) for every layer of the table in two launches."""
+    dev, n = table
+    check(_lib.lib().unetrir_cast_weights_batched_bf16(dev.data_ptr(), n, _stream()), "cast_weights_batched")
+
+
 def add_f32_to_bf16(a: Act, b: Act, y: Act):
     """y = a + b with a, y bf16 and b fp32, dense buffers (Add() of dl_models/u_net.py:229 in the bf16 trunk)."""
     check(_lib.lib().unetrir_add_f32_to_bf16(_p(a), _p(b), _p(y), a.base.numel(), _stream()), "add_f32_to_bf16")
