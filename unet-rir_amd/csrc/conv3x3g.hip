@@ -164,11 +164,13 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 #pragma unroll 1
         for (int dx = 0; dx < 3; ++dx) {
             // ---- prefetch: weight tile of step s+2 (ring slot (dx+2)%3), patch of the next chunk
+            if constexpr (!(VAR & 16)) {              // (VAR bits 2..4: timing ablations only, results are invalid)
             if (dx == 0) {
                 issue_w(ch, 2, 2);
                 if (more) issue_p(ch + 1);
             } else if (more) {
                 issue_w(ch + 1, dx - 1, dx - 1);
+            }
             }
             const uint32_t a_dx = a_chunk + dx * 64;
             const uint32_t a_swz = ((l31 + dx) & 12) << 2;
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             }
             }
             // ---- retire what the next step reads; younger DMAs stay in flight across the barrier
+            if constexpr (!(VAR & 8)) {
             if (dx == 0) {
                 if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W(s+2) + P(ch+1) may remain
                 else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");        // W(s+2) may remain
@@ -258,10 +261,12 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
                 if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // W(s+2) may remain; P(ch+1) is older: retired
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (!(VAR & 4)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
     }
+    if constexpr ((VAR & 28) != 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
     // ---- epilogue through LDS (all DMAs retired, every wave past the last barrier), two image rows of the wave at a time:
     // acc[i][j] holds D[n = 32j + (r&3) + 8(r>>2) + 4*hi][pixel column = l31] of image row y0 + 4*wm + i.
@@ -374,7 +379,10 @@ bool conv3x3g_applies(const Conv3Args& a) {
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);
     static const int var = [] { const char* e = getenv("UNETRIR_G_VAR"); return e ? atoi(e) : 2; }();
-    if (var & 2) hipLaunchKernelGGL(conv3x3g_bf16_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    // UNETRIR_G_VAR=30: timing ablation (no DMA, no vmcnt wait, no barrier in the K loop; results invalid): measured 102 us vs
+    // 120 us for 512->512 @ 32x32, i.e. the synchronisation and staging cost 15 %, the rest is fragment reads + MFMA issue.
+    if (var == 30) hipLaunchKernelGGL(conv3x3g_bf16_kernel<30>, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    else if (var & 2) hipLaunchKernelGGL(conv3x3g_bf16_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     else if (var & 1) hipLaunchKernelGGL(conv3x3g_bf16_kernel<1>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(conv3x3g_bf16_kernel<0>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     return (int)hipGetLastError();
