@@ -24,6 +24,10 @@
 #include <stdlib.h>
 #include "kernels.h"
 
+// The epilogue staging tile is private to a wave: LDS operations of one wave execute in issue order, so its reads see its
+// own earlier writes without a workgroup barrier; this only stops the compiler from moving LDS accesses across the point.
+#define WAVE_LDS_FENCE() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
+        if (half) WAVE_LDS_FENCE();
         if constexpr (S16) {
             // acc16[i][h][t][e] = D[n = 16t + 4*lq + e][pixel column = 16h + l15] of image row y0 + 4*wm + i
 #pragma unroll
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
                 }
             }
         }
-        __syncthreads();
+        WAVE_LDS_FENCE();
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int p = ps * 8 + pl;

@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include "kernels.h"
 
+// The epilogue staging tile is private to a wave: LDS operations of one wave execute in issue order, so its reads see its
+// own earlier writes without a workgroup barrier; this only stops the compiler from moving LDS accesses across the point.
+#define WAVE_LDS_FENCE() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -43,6 +47,7 @@ constexpr int HSMEM = 2 * HP_BYTES + 3 * HW_BYTES;        // 59392
 static_assert(HP_BYTES >= 4 * 32 * HSROW && HW_BYTES >= 4 * 64 * 2 * 4, "epilogue staging / statistics regions");
 }  // namespace
 
+template <int ABL>      // ABL: timing ablations only (1: no DMA in the K loop, 2: no vmcnt wait / barrier); results invalid
 __global__ __launch_bounds__(256, 2) void conv3x3h_bf16_kernel(const Conv3Args a) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[HSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
@@ -153,10 +158,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_bf16_kernel(const Conv3Args a
         for (int r6 = 0; r6 < 6; ++r6, ++s) {
             const int kk = r6 >= 3 ? 1 : 0, dx = r6 - 3 * kk;
             // ---- prefetch: weights of step s+2; at dx == 0 the patch half that the step three ahead starts on
-            const bool w_issued = s + 2 < nsteps || has_next;        // the next tile starts on the same weight tiles
+            const bool w_issued = (s + 2 < nsteps || has_next) && !(ABL & 1);   // the next tile starts on the same weight tiles
             if (w_issued) issue_w(s + 2 < nsteps ? s + 2 : s + 2 - nsteps);
             bool p_issued = false;
-            if (dx == 0) {
+            if (dx == 0 && !(ABL & 1)) {
                 if (kk == 0) { issue_p(rs_in, pa, ch, 1); p_issued = true; }
                 else if (more) { issue_p(rs_in, pa, ch + 1, 0); p_issued = true; }
                 else if (has_next) {                                   // first patch half of the next tile
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_bf16_kernel(const Conv3Args a
             int allow = w_issued ? 2 : 0;
             if (dx == 0) allow += p_issued ? 5 : 0;
             else if (dx == 1) allow += (kk == 0 || more || has_next) ? 5 : 0;
+            if constexpr (ABL & 2) { asm volatile("" ::: "memory"); continue; }
             if (allow == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else if (allow == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else if (allow == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_bf16_kernel(const Conv3Args a
     for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i) __syncthreads();
+        if (i) WAVE_LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_bf16_kernel(const Conv3Args a
                 *reinterpret_cast<bf16x4*>(stage + l31 * HSROW + n * 2) = o;
             }
         }
-        __syncthreads();
+        WAVE_LDS_FENCE();
         const int y = y0 + 4 * wm + i;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -309,6 +315,10 @@ bool conv3x3h_applies(const Conv3Args& a) {
 int launch_conv3x3h_bf16(const Conv3Args& a, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + HTR - 1) / HTR) * ((a.W + 31) / 32);
     static const int cap = [] { const char* e = getenv("UNETRIR_H_GRID"); return e ? atoi(e) : 512; }();   // 2 persistent workgroups per CU
-    hipLaunchKernelGGL(conv3x3h_bf16_kernel, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(256), 0, s, a);
+    static const int abl = [] { const char* e = getenv("UNETRIR_H_ABL"); return e ? atoi(e) : 0; }();
+    const dim3 grid((unsigned)(tiles < cap ? tiles : cap));
+    if (abl == 1) hipLaunchKernelGGL(conv3x3h_bf16_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (abl == 3) hipLaunchKernelGGL(conv3x3h_bf16_kernel<3>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv3x3h_bf16_kernel<0>, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

@@ -14,6 +14,10 @@
 #include <stdint.h>
 #include "kernels.h"
 
+// The epilogue staging tile is private to a wave: LDS operations of one wave execute in issue order, so its reads see its
+// own earlier writes without a workgroup barrier; this only stops the compiler from moving LDS accesses across the point.
+#define WAVE_LDS_FENCE() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3r_bf16_kernel(const Conv3Args a
     for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();
+        if (half) WAVE_LDS_FENCE();
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3r_bf16_kernel(const Conv3Args a
                 }
             }
         }
-        __syncthreads();
+        WAVE_LDS_FENCE();
 #pragma unroll
         for (int ps = 0; ps < 64 / PPP; ++ps) {
             const int p = ps * PPP + pl;
