@@ -365,34 +365,47 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// out[i] = sum_s part[s][i] + reg * w[i].  Block = 32 float4 outputs x 8 split groups: group g sums slabs g, g+8, ...
-// (independent loads in flight), then the 8 group sums are added in fixed order -> bit-reproducible.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
-                                                            float* __restrict__ out, float reg, const float* __restrict__ w) {
-    __shared__ float4 red[8][32];
-    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const size_t i4 = ((size_t)blockIdx.x * 32 + lane) * 4;
+// out[i] = sum_s part[s][i] + reg * w[i].  Block = 64 float4 outputs (one full wave: 1 KB contiguous per load) x G split
+// groups (waves): group g sums slabs g, g+G, ... in order with 8 independent loads in flight, then the G group sums are
+// added in fixed order -> bit-reproducible.  G follows the split count so that no wave idles when there are few slabs.
+template <int G>
+__global__ __launch_bounds__(64 * G) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
+                                                               float* __restrict__ out, float reg, const float* __restrict__ w) {
+    __shared__ float4 red[G][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t i4 = ((size_t)blockIdx.x * 64 + lane) * 4;
     const bool full = i4 + 3 < n;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (full) {
-#pragma unroll 4
-        for (int k = grp; k < nsplit; k += 8) {
-            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * n + i4);
+        const float* p = part + i4;
+        int k = grp;
+        for (; k + 7 * G < nsplit; k += 8 * G) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + u * G) * n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; k += G) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * n);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     } else if (i4 < n) {
         float* sp = &s.x;
-        for (int k = grp; k < nsplit; k += 8)
+        for (int k = grp; k < nsplit; k += G)
             for (size_t i = i4; i < n; ++i) sp[i - i4] += part[(size_t)k * n + i];
     }
-    red[grp][lane] = s;
-    __syncthreads();
-    if (grp != 0 || i4 >= n) return;
+    if (G > 1) {
+        red[grp][lane] = s;
+        __syncthreads();
+        if (grp != 0) return;
 #pragma unroll
-    for (int g = 1; g < 8; ++g) {
-        const float4 v = red[g][lane];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int g = 1; g < G; ++g) {
+            const float4 v = red[g][lane];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
+    if (i4 >= n) return;
     if (full) {
         if (reg != 0.f) {
             const float4 v = *reinterpret_cast<const float4*>(w + i4);
@@ -516,7 +529,11 @@ int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* 
 
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s) {
     const size_t n4 = (n + 3) / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, s, part, nsplit, n, out, reg, w);
+    const dim3 grid((unsigned)((n4 + 63) / 64));
+    if (nsplit >= 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(512), 0, s, part, nsplit, n, out, reg, w);
+    else if (nsplit >= 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, s, part, nsplit, n, out, reg, w);
+    else if (nsplit >= 2) hipLaunchKernelGGL(splitk_reduce_kernel<2>, grid, dim3(128), 0, s, part, nsplit, n, out, reg, w);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, grid, dim3(64), 0, s, part, nsplit, n, out, reg, w);
     return (int)hipGetLastError();
 }
 
