@@ -72,11 +72,21 @@ struct F32 {
     static constexpr int is_bf16 = 0;
     using T = float; using Args = IgemmArgs;
     static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd(a, s); }
+    static int launch_classes(const Args* a, hipStream_t s) {
+        for (int i = 0; i < 4; ++i) { const int err = launch_igemm_fwd(a[i], s); if (err) return err; }
+        return 0;
+    }
 };
 struct BF16 {
     static constexpr int is_bf16 = 1;
     using T = __bf16; using Args = IgemmArgsH;
     static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd_bf16(a, s); }
+    static int launch_classes(const Args* a, hipStream_t s) {
+        static const bool batched = [] { const char* e = getenv("UNETRIR_PARITY_X4"); return !(e && e[0] == '0'); }();
+        if (batched) return launch_igemm_fwd_bf16_x4(a, s);
+        for (int i = 0; i < 4; ++i) { const int err = launch_igemm_fwd_bf16(a[i], s); if (err) return err; }
+        return 0;
+    }
 };
 
 // ---- Conv2D forward: iteration grid = output grid ----
@@ -143,6 +153,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
     }
     // stride 2: one launch per output parity class (ay, ax); q = 2p' + a, p = p' + (a - off)/2
     a.g.PH = (g->H + 1) / 2; a.g.PW = (g->W + 1) / 2; a.g.SI = 1; a.g.SO = 2;
+    typename P::Args cls[4];
     for (int ay = 0; ay < 2; ++ay)
         for (int ax = 0; ax < 2; ++ax) {
             int nt = 0;
@@ -156,10 +167,9 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
                 }
             }
             a.g.ntaps = nt; a.g.ooy = ay; a.g.oox = ax;
-            const int err = P::launch(a, s);
-            if (err) return err;
+            cls[ay * 2 + ax] = a;
         }
-    return 0;
+    return P::launch_classes(cls, s);       // bf16: the four classes share one grid
 }
 
 void wgrad_args(const unetrir_conv_geom* g, int ldx, int lddy, WgradArgs* a) {

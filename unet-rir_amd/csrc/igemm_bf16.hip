@@ -29,7 +29,7 @@ __device__ __forceinline__ int xcd_remap_h(int bid, int nwg) {
 // forward-type kernel (Conv2D fwd, Conv2DTranspose fwd, every data gradient)
 // ------------------------------------------------------------------------------------------------
 template <int BN_, bool UNIFORM>
-__global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a) {
+__device__ __forceinline__ void igemm_fwd_bf16_body(const IgemmArgsH& a, const int block_id, const int n_blocks) {
     constexpr int NSUB = BN_ / 64;
     constexpr int NB = BN_ / 32;
     __shared__ __attribute__((aligned(16))) __bf16 smem_h[(BM + BN_) * LDH];     // A tile, B tile; reused by the epilogue
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a)
     if (tid < UNETRIR_MAX_TAPS) s_tap[tid] = a.g.tap[tid];
 
     const int ntN = (a.g.N + BN_ - 1) / BN_;
-    const int id = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int id = xcd_remap_h(block_id, n_blocks);
     const int mt = id / ntN, nt = id - mt * ntN;
     const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
     const long long m0 = (long long)mt * BM;
@@ -222,6 +222,18 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a)
             }
         }
     }
+}
+
+template <int BN_, bool UNIFORM>
+__global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel(const IgemmArgsH a) {
+    igemm_fwd_bf16_body<BN_, UNIFORM>(a, blockIdx.x, gridDim.x);
+}
+
+// four launches of the same shape in one grid (blockIdx.y): the output-parity classes of a stride-2 transposed conv
+struct IgemmArgsH4 { IgemmArgsH a[4]; };
+template <int BN_, bool UNIFORM>
+__global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel4(const IgemmArgsH4 a4) {
+    igemm_fwd_bf16_body<BN_, UNIFORM>(a4.a[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -437,6 +449,25 @@ int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s) {
     } else {
         if (uniform) hipLaunchKernelGGL((igemm_fwd_bf16_kernel<64, true>), dim3((unsigned)mt), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((igemm_fwd_bf16_kernel<64, false>), dim3((unsigned)mt), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_igemm_fwd_bf16_x4(const IgemmArgsH* a, hipStream_t s) {
+    const long long M = (long long)a[0].g.B * a[0].g.PH * a[0].g.PW;
+    if (M <= 0 || a[0].g.N <= 0) return 0;
+    const long long mt = (M + BM - 1) / BM;
+    const bool uniform = (a[0].g.C % BKH) == 0;
+    IgemmArgsH4 a4;
+    for (int i = 0; i < 4; ++i) a4.a[i] = a[i];
+    if (a[0].g.N > 64) {
+        const dim3 grid((unsigned)(mt * ((a[0].g.N + 127) / 128)), 4);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_bf16_kernel4<128, true>), grid, dim3(256), 0, s, a4);
+        else hipLaunchKernelGGL((igemm_fwd_bf16_kernel4<128, false>), grid, dim3(256), 0, s, a4);
+    } else {
+        const dim3 grid((unsigned)mt, 4);
+        if (uniform) hipLaunchKernelGGL((igemm_fwd_bf16_kernel4<64, true>), grid, dim3(256), 0, s, a4);
+        else hipLaunchKernelGGL((igemm_fwd_bf16_kernel4<64, false>), grid, dim3(256), 0, s, a4);
     }
     return (int)hipGetLastError();
 }

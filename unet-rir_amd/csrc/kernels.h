@@ -77,6 +77,7 @@ struct Wgrad3ArgsH {
     int patches_per_split, npy, npx;
 };
 int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
+int launch_igemm_fwd_bf16_x4(const IgemmArgsH* a, hipStream_t s);
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 #define WGRAD3X3R_NOT_TAKEN (-12345)
 int launch_wgrad3x3r_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
