@@ -402,6 +402,17 @@ __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const unetrir
     if (!d.same) return;
     __bf16* o = (__bf16*)d.same;
     const size_t total = (size_t)d.N * d.T * d.Cp;
+    if (d.C == d.Cp && (total & 7) == 0 && (((uintptr_t)d.w | (uintptr_t)o) & 15) == 0) {     // flat copy, 8 elements per thread
+        const size_t n8 = total >> 3;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+            const float4 a = *reinterpret_cast<const float4*>(d.w + i * 8), b = *reinterpret_cast<const float4*>(d.w + i * 8 + 4);
+            bf16x8 v;
+            v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+            v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+            *reinterpret_cast<bf16x8*>(o + i * 8) = v;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % d.Cp);
         const size_t nt = i / d.Cp;
@@ -519,7 +530,7 @@ int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, 
 }
 
 int launch_cast_weights_batched(const unetrir_cast_desc* desc_dev, int n_layers, hipStream_t s) {
-    hipLaunchKernelGGL(cast_weights_batched_kernel, dim3(128, n_layers), dim3(256), 0, s, desc_dev);
+    hipLaunchKernelGGL(cast_weights_batched_kernel, dim3(256, n_layers), dim3(256), 0, s, desc_dev);
     hipLaunchKernelGGL(transpose_cast_weights_batched_kernel, dim3(256, n_layers), dim3(256), 0, s, desc_dev);
     return (int)hipGetLastError();
 }
