@@ -219,7 +219,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nsla
     coef[C + c] = (float)(ss / (double)P);
 }
 
-// y = x*scale + shift (ReLU optional), one 16-byte vector per lane over [P][C]
+// y = x*scale + shift (ReLU optional), one 16-byte vector per lane over [P][C].  The grid stride is a multiple of the
+// channel-vector count whenever C/V divides the 256-thread block (every layer here), so a thread keeps ONE channel group
+// and its per-channel parameters live in registers for the whole loop instead of being re-fetched per element.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long P, int C,
                                                        const float* __restrict__ affine, int relu,
@@ -228,8 +230,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     constexpr int V = VecOf<T>::N;
     const int CQ = C / V;
     const long long total = P * CQ;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float sl = relu == 2 ? 0.3f : 0.f;
+    if (stride % CQ == 0) {
+        const int c0 = (int)(i0 % CQ) * V;
+        float sc[V], sh[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { sc[k] = affine ? affine[c0 + k] : 1.f; sh[k] = affine ? affine[C + c0 + k] : 0.f; }
+        const long long pstep = stride / CQ;
+        for (long long p = i0 / CQ; p < P; p += pstep) {
+            float r[V];
+            ldv(x + (size_t)p * ldx + c0, r);
+#pragma unroll
+            for (int k = 0; k < V; ++k) r[k] = r[k] * sc[k] + sh[k];
+            if (addend) {     // Add() in front of the activation (residual blocks, dl_models/res_ae.py:334, :478)
+                float ad[V];
+                ldv(addend + (size_t)p * ldadd + c0, ad);
+#pragma unroll
+                for (int k = 0; k < V; ++k) r[k] += ad[k];
+            }
+            if (relu) {       // 1: ReLU; 2: keras LeakyReLU() (alpha = 0.3)
+#pragma unroll
+                for (int k = 0; k < V; ++k) r[k] = r[k] > 0.f ? r[k] : sl * r[k];
+            }
+            stv(y + (size_t)p * ldy + c0, r);
+        }
+        return;
+    }
+    for (long long i = i0; i < total; i += stride) {
         const long long p = i / CQ;
         const int c0 = (int)(i - p * CQ) * V;
         float r[V];
@@ -238,14 +267,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] = r[k] * affine[c0 + k] + affine[C + c0 + k];
         }
-        if (addend) {     // Add() in front of the activation (residual blocks, dl_models/res_ae.py:334, :478)
+        if (addend) {
             float ad[V];
             ldv(addend + (size_t)p * ldadd + c0, ad);
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] += ad[k];
         }
-        if (relu) {       // 1: ReLU; 2: keras LeakyReLU() (alpha = 0.3)
-            const float sl = relu == 2 ? 0.3f : 0.f;
+        if (relu) {
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] = r[k] > 0.f ? r[k] : sl * r[k];
         }
@@ -264,8 +292,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     constexpr int V = VecOf<T>::N;
     const int CQ = C / V;
     const long long total = P * CQ;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (affine && stride % CQ == 0) {
+        const int c0 = (int)(i0 % CQ) * V;
+        float sc[V], sh[V], mu[V], rs[V], c1[V], c2[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            sc[k] = affine[c0 + k]; sh[k] = affine[C + c0 + k];
+            mu[k] = saved[c0 + k]; rs[k] = saved[C + c0 + k]; c1[k] = coef[c0 + k]; c2[k] = coef[C + c0 + k];
+        }
+        const long long pstep = stride / CQ;
+        for (long long p = i0 / CQ; p < P; p += pstep) {
+            float xv[V], gv[V], out[V];
+            ldv(x + (size_t)p * ldx + c0, xv);
+            ldv(da + (size_t)p * ldda + c0, gv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float a = xv[k] * sc[k] + sh[k];
+                const float g = (relu && !(a > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
+                const float xh = (xv[k] - mu[k]) * rs[k];
+                out[k] = sc[k] * (g - c1[k] - xh * c2[k]);
+            }
+            stv(dx + (size_t)p * lddx + c0, out);
+        }
+        return;
+    }
+    for (long long i = i0; i < total; i += stride) {
         const long long p = i / CQ;
         const int c0 = (int)(i - p * CQ) * V;
         float xv[V], gv[V], out[V];
