@@ -5,6 +5,7 @@
 // these kernels are bound by HBM bytes, not by flops).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <math.h>
 #include "kernels.h"
 
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const long long total = P * CQ;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nohoist = relu & 256; relu &= 255;     // bit 8: A/B switch (UNETRIR_BN_HOIST=0), forces the re-fetching loop
     const float sl = relu == 2 ? 0.3f : 0.f;
-    if (stride % CQ == 0) {
+    if (stride % CQ == 0 && !nohoist) {
         const int c0 = (int)(i0 % CQ) * V;
         float sc[V], sh[V];
 #pragma unroll
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const long long total = P * CQ;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (affine && stride % CQ == 0) {
+    const int nohoist = relu & 256; relu &= 255;
+    if (affine && stride % CQ == 0 && !nohoist) {
         const int c0 = (int)(i0 % CQ) * V;
         float sc[V], sh[V], mu[V], rs[V], c1[V], c2[V];
 #pragma unroll
@@ -572,6 +575,10 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+static inline int bn_nohoist_flag() {
+    static const int f = [] { const char* e = getenv("UNETRIR_BN_HOIST"); return (e && e[0] == '0') ? 256 : 0; }();
+    return f;
+}
 static inline bool chan_ok(const void* x, int ld, long long P, int C, int vec = 4) {
     return x && P > 0 && C > 0 && C % vec == 0 && ld >= C && ld % vec == 0 && ((uintptr_t)x & 15) == 0;
 }
@@ -593,7 +600,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
 template <typename T>
 int bn_apply_impl(const T* x, int ldx, long long P, int C, const float* affine, int relu, T* y, int ldy, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !y || ldy < C || ldy % VecOf<T>::N) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, x, ldx, P, C, affine, relu, y, ldy);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, x, ldx, P, C, affine, relu | bn_nohoist_flag(), y, ldy);
     return (int)hipGetLastError();
 }
 
@@ -610,7 +617,7 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
-                       (const float*)coef, relu, dx, lddx);
+                       (const float*)coef, relu | bn_nohoist_flag(), dx, lddx);
     return (int)hipGetLastError();
 }
 

@@ -150,19 +150,22 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_h;
 
 #define HW_XL 80              // x row stride in LDS, elements (160 B)
 #define HW_DL 264             // D' (n,kw) stride, elements (528 B)
+#define HW_ROWS 16            // dy rows per workgroup step: 2 workgroups per CU x 256 CUs = 512 blocks for 32 x 256 rows
 
-__global__ __launch_bounds__(256) void head_wgrad_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W, int C,
-                                                              const __bf16* __restrict__ dy, int lddy,
-                                                              float* __restrict__ part) {
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[2][256 * HW_XL];      // 81920 B
-    __shared__ __attribute__((aligned(16))) __bf16 Dp[6][16 * HW_DL];       // 50688 B
+__global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W, int C,
+                                                                 const __bf16* __restrict__ dy, int lddy,
+                                                                 float* __restrict__ part) {
+    // 78.2 KB of LDS: two workgroups per CU hide each other's row loads (one x row buffer; (n,kw) rows 12..15 are zero
+    // fragments made in registers)
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[256 * HW_XL];         // 40960 B
+    __shared__ __attribute__((aligned(16))) __bf16 Dp[6][12 * HW_DL];       // 38016 B
     __shared__ __attribute__((aligned(16))) __bf16 dyrow[2][272];           // dy row, planar, 3 zero pixels left / 13 right
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int c0 = blockIdx.y * 64;
-    const int nrb = (H + HM_ROWS - 1) / HM_ROWS;
+    const int nrb = (H + HW_ROWS - 1) / HW_ROWS;
 
-    for (int i = tid; i < 6 * 16 * HW_DL; i += 256) (&Dp[0][0])[i] = (__bf16)0.f;   // rows 12..15 and the pads stay zero
+    for (int i = tid; i < 6 * 12 * HW_DL; i += 256) (&Dp[0][0])[i] = (__bf16)0.f;   // the pads stay zero
     for (int i = tid; i < 2 * 272; i += 256) (&dyrow[0][0])[i] = (__bf16)0.f;
 
     f32x4 acc[6];
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(256) void head_wgrad_mfma_kernel(const __bf16* __re
     uint4 rx[8];
     for (int blk = blockIdx.x; blk < B * nrb; blk += gridDim.x) {
         const int img = blk / nrb, rb = blk - img * nrb;
-        const int y0 = rb * HM_ROWS;
-        const int nrows = (H - y0) < HM_ROWS ? (H - y0) : HM_ROWS;
+        const int y0 = rb * HW_ROWS;
+        const int nrows = (H - y0) < HW_ROWS ? (H - y0) : HW_ROWS;
         const __bf16* xi = x + (size_t)img * H * W * ldx + c0 + g8 * 8;
         const __bf16* di = dy + (size_t)img * H * W * lddy;
         auto load_x = [&](int iy) {
@@ -187,21 +190,23 @@ __global__ __launch_bounds__(256) void head_wgrad_mfma_kernel(const __bf16* __re
                 rx[j] = v;
             }
         };
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        auto load_dy = [&](int r) {                   // dy row y0 + r (zeros outside the block / image columns)
+            bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
+            if (r < nrows && tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)(y0 + r) * W + tid) * lddy);
+            return d;
+        };
         load_x(y0 - 2);
+        bf16x2 dnext = load_dy(0);
         const int nsteps = nrows + 5;
         for (int i = 0; i < nsteps; ++i) {
             const int iy = y0 - 2 + i;
-            __syncthreads();                          // previous step's MFMAs are done with Xs[(i+1)&1]'s twin and with the ring
-            __bf16* Xb = Xs[i & 1];
+            __syncthreads();                          // the previous step's MFMAs are done with the x row and with the ring
+            __bf16* Xb = Xs;
 #pragma unroll
             for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(Xb + (qsub + 32 * j) * HW_XL + g8 * 8) = rx[j];
             const bool newdy = i < nrows;             // dy row y0 + i enters the ring (vertical tap kh = 0 of this x row)
-            if (newdy) {
-                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-                bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
-                if (tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)(y0 + i) * W + tid) * lddy);
-                dyrow[0][tid + 3] = d[0]; dyrow[1][tid + 3] = d[1];
-            }
+            if (newdy) { dyrow[0][tid + 3] = dnext[0]; dyrow[1][tid + 3] = dnext[1]; }
             __syncthreads();
             if (newdy) {
                 __bf16* Db = Dp[(y0 + i) % 6];
@@ -210,24 +215,36 @@ __global__ __launch_bounds__(256) void head_wgrad_mfma_kernel(const __bf16* __re
 #pragma unroll
                     for (int kw = 0; kw < 6; ++kw) Db[(n * 6 + kw) * HW_DL + tid] = dyrow[n][tid - kw + 2 + 3];
             }
-            if (i + 1 < nsteps) load_x(iy + 1);
+            if (i + 1 < nsteps) { load_x(iy + 1); dnext = load_dy(i + 1); }
             __syncthreads();
             if ((unsigned)iy < (unsigned)H) {
+                // ring slot of each vertical tap's dy row (wave-uniform), -1 where that row is outside the block
+                int doff[6];
 #pragma unroll
+                for (int kh = 0; kh < 6; ++kh) {
+                    const int orow = i - kh;
+                    doff[kh] = (orow < 0 || orow >= nrows) ? -1 : ((y0 + orow) % 6) * (12 * HW_DL);
+                }
+                const int r = l15 >> 2, p = l15 & 3;
+                const __bf16* xr0 = Xb + (4 * lq + r) * HW_XL + wave * 16 + 4 * p;
+                const __bf16* dr0 = &Dp[0][0] + (l15 < 12 ? l15 : 0) * HW_DL + 4 * lq;
+#pragma unroll 2
                 for (int ks = 0; ks < 8; ++ks) {
                     // B operand (x, transposed read): group lq supplies pixel rows ks*32 + 4*lq + r (+16), channels wave*16 + 4p..
-                    const int r = l15 >> 2, p = l15 & 3;
-                    const __bf16* xr = Xb + (ks * 32 + 4 * lq + r) * HW_XL + wave * 16 + 4 * p;
+                    const __bf16* xr = xr0 + ks * 32 * HW_XL;
                     const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)xr);
                     const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_h*)(xr + 16 * HW_XL));
                     const bf16x8 fb = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
                     for (int kh = 0; kh < 6; ++kh) {
-                        const int orow = i - kh;      // dy row y0 + orow
-                        if (orow < 0 || orow >= nrows) continue;
-                        const __bf16* dr = Dp[(y0 + orow) % 6] + l15 * HW_DL + ks * 32 + 4 * lq;
-                        const bf16x4 alo = *reinterpret_cast<const bf16x4*>(dr);
-                        const bf16x4 ahi = *reinterpret_cast<const bf16x4*>(dr + 16);
+                        if (doff[kh] < 0) continue;
+                        const __bf16* dr = dr0 + doff[kh] + ks * 32;
+                        bf16x4 alo = *reinterpret_cast<const bf16x4*>(dr);
+                        bf16x4 ahi = *reinterpret_cast<const bf16x4*>(dr + 16);
+                        if (l15 >= 12) {                  // (n,kw) rows 12..15 do not exist: zero fragments
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { alo[e] = (__bf16)0.f; ahi[e] = (__bf16)0.f; }
+                        }
                         const bf16x8 fa = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
                         acc[kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[kh], 0, 0, 0);
                     }
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256) void head_wgrad_mfma_kernel(const __bf16* __re
 
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
                            int* nblk_out, hipStream_t s) {
-    int nblk = B * ((H + HM_ROWS - 1) / HM_ROWS);
+    int nblk = B * ((H + HW_ROWS - 1) / HW_ROWS);
     if (nblk > max_blocks) nblk = max_blocks;
     *nblk_out = nblk;
     hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nblk, C / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
