@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nohoist = relu & 256; relu &= 255;     // bit 8: A/B switch (UNETRIR_BN_HOIST=0), forces the re-fetching loop
     const float sl = relu == 2 ? 0.3f : 0.f;
-    if (stride % CQ == 0 && !nohoist) {
+    if (stride % CQ == 0 && !nohoist && addend != nullptr) {   // measured: hoisting pays for the 3-input forms only
         const int c0 = (int)(i0 % CQ) * V;
         float sc[V], sh[V];
 #pragma unroll
