@@ -4,6 +4,8 @@ gradients per tensor max|g-g*| <= 1e-3 max|g*| and relative L2 error <= 1e-4 (ob
 Adam step atol 2e-5.  The one large case (144x160, ~4e5 ReLU inputs) uses max-norm 2e-2 / L2 1e-2 instead: there a
 pre-activation within one fp32 ulp of zero takes the other ReLU branch than in the fp64 oracle, which moves a single
 element of one layer's gradient by O(1) of its value (seen: 1 element of enc3; everything upstream of it stays at 2e-6)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -309,3 +311,43 @@ def test_graph_engine_mode0_equals_hand_schedule(U):
     g1, g2 = e1.export_keras_grads(), e2.export_keras_grads()
     for n in g1:
         assert float((g1[n] - g2[n]).abs().max()) <= 1e-6 * (float(g1[n].abs().max()) + 1e-12) + 1e-9, n
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_and_epoch_loop(U, tmp_path):
+    """main_training.py:171-172, :336-390: numbered checkpoints (keep 2) restore variables, BatchNorm moving statistics
+    and the Adam state so that training continues bit-identically; the epoch loop reports the amplitude / phase means."""
+    cfg, Pn, (spec_in, emb, spec_out), eng = _bf16_case(U, 32, 32, 8, 2)
+    t = lambda a: torch.tensor(a).to(DEV)
+    batch = (t(spec_in), t(emb), t(spec_out))
+    tr = U.Trainer(eng, lr=1e-3, dropout=False)
+    mgr = U.CheckpointManager(tr, str(tmp_path), max_to_keep=2)
+    for _ in range(3):
+        tr.step(*batch)
+        mgr.save()
+    names = sorted(f for f in os.listdir(tmp_path) if f.endswith(".pt"))
+    assert names == ["ckpt-2.pt", "ckpt-3.pt"]                     # oldest deleted
+    tr.step(*batch)                                                # the step a resumed run must reproduce
+    torch.cuda.synchronize()
+    want_theta, want_m = eng.theta.clone(), eng.adam_m.clone()
+    want_mov = {k: v.clone() for k, v in eng.moving.items()}
+    # a fresh engine (different initial weights), restored from the latest checkpoint
+    eng2 = U.UNetEngine(32, 32, 2, F0=8, dtype="bf16", device=DEV)
+    tr2 = U.Trainer(eng2, lr=1e-3, dropout=False)
+    mgr2 = U.CheckpointManager(tr2, str(tmp_path), max_to_keep=2)
+    assert mgr2.latest_checkpoint.endswith("ckpt-3.pt")
+    mgr2.restore()
+    assert eng2.adam_t == 3
+    tr2.step(*batch)
+    torch.cuda.synchronize()
+    assert torch.equal(eng2.theta, want_theta) and torch.equal(eng2.adam_m, want_m)
+    for k in want_mov:
+        assert torch.equal(eng2.moving[k], want_mov[k])
+    # epoch loop: 3 epochs x 2 steps, validation pass leaves the model untouched, checkpoints at epochs 0 and 2
+    before = eng2.theta.clone()
+    hist = U.fit(tr2, lambda e: [batch, batch], 3, val_batches=lambda e: [batch], manager=mgr2, lr0=0.0, log=None)
+    assert [h["epoch"] for h in hist] == [1, 2, 3] and "checkpoint" in hist[0] and "checkpoint" not in hist[1]
+    assert all(np.isfinite(h[k]) for h in hist for k in ("train_loss", "train_amp", "train_phase", "val_loss", "val_amp", "val_phase"))
+    assert abs(hist[0]["train_loss"] - (0.9 * hist[0]["train_amp"] + 0.1 * hist[0]["train_phase"])) < 1e-5
+    assert torch.equal(eng2.theta, before)                         # lr 0: nothing moved, validation updates nothing
+    assert U.lr_schedule(1e-3, 79) == 1e-3 and abs(U.lr_schedule(1e-3, 80) - 1e-3 * 0.9) < 1e-12

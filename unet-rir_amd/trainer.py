@@ -122,3 +122,106 @@ class Trainer:
         value strategy.reduce(SUM, ...) returns (main_training.py:326)."""
         eng = self.engine
         return float(eng.loss_out[0]) + float(eng.reg_out[0])
+
+
+class CheckpointManager:
+    """tf.train.CheckpointManager(checkpoint, directory, max_to_keep=2) of main_training.py:171-172: numbered checkpoints
+    holding the model variables (incl. the BatchNorm moving statistics) and the optimizer state, oldest ones deleted."""
+
+    def __init__(self, trainer: "Trainer", directory, max_to_keep=2):
+        self.trainer, self.directory, self.max_to_keep = trainer, directory, max_to_keep
+        os.makedirs(directory, exist_ok=True)
+
+    def _paths(self):
+        out = []
+        for f in os.listdir(self.directory):
+            if f.startswith("ckpt-") and f.endswith(".pt"):
+                try:
+                    out.append((int(f[5:-3]), os.path.join(self.directory, f)))
+                except ValueError:
+                    pass
+        return sorted(out)
+
+    @property
+    def latest_checkpoint(self):
+        p = self._paths()
+        return p[-1][1] if p else None
+
+    def save(self, epoch=None):
+        """manager.save() (main_training.py:364-365).  Rank 0 only writes in a multi-process job."""
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return None
+        eng = self.trainer.engine
+        p = self._paths()
+        n = (p[-1][0] + 1) if p else 1
+        path = os.path.join(self.directory, f"ckpt-{n}.pt")
+        state = {
+            "format": 1, "epoch": epoch, "lr": self.trainer.lr, "adam_t": eng.adam_t,
+            "layout": [(k, tuple(s_.shape), int(s_.offset)) for k, s_ in eng.specs.items()],
+            "theta": eng.theta.detach().cpu(), "adam_m": eng.adam_m.detach().cpu(), "adam_v": eng.adam_v.detach().cpu(),
+            "moving": {k: v.detach().cpu() for k, v in eng.moving.items()},
+        }
+        tmp = path + ".tmp"
+        torch.save(state, tmp)
+        os.replace(tmp, path)
+        for _, old in self._paths()[:-self.max_to_keep]:
+            os.remove(old)
+        return path
+
+    def restore(self, path=None):
+        """checkpoint.restore(manager.latest_checkpoint): variables, moving statistics and Adam slots / step count."""
+        path = path or self.latest_checkpoint
+        if path is None:
+            return None
+        eng = self.trainer.engine
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        layout = [(k, tuple(s_.shape), int(s_.offset)) for k, s_ in eng.specs.items()]
+        if [tuple(x) for x in state["layout"]] != layout:
+            raise ValueError("checkpoint was written for a different model configuration")
+        eng.theta.copy_(state["theta"]); eng.adam_m.copy_(state["adam_m"]); eng.adam_v.copy_(state["adam_v"])
+        for k, v in state["moving"].items():
+            eng.moving[k].copy_(v)
+        eng.adam_t = int(state["adam_t"])
+        eng.t_dirty = True
+        return state.get("epoch")
+
+
+def fit(trainer: "Trainer", train_batches, n_epochs, val_batches=None, manager: CheckpointManager = None, lr0=None,
+        lr_exp_decay=(True, 80), start_epoch=0, log=print):
+    """The epoch loop of main_training.py:336-390: exponential rate from epoch 80, running means of the amplitude / phase
+    loss terms, a checkpoint every second epoch.  `train_batches` / `val_batches` are callables returning an iterable of
+    (spec_in, emb, spec_out) per-replica shards for the epoch.  As in the reference the validation pass runs the model
+    with training=True semantics (main_training.py:297-300: batch statistics, dropout active) but updates nothing."""
+    eng = trainer.engine
+    lr0 = trainer.lr if lr0 is None else lr0
+    inv = 1.0 / (2.0 * eng.H * eng.W * eng.B * trainer.world_size)      # loss_out[1:3] are raw sums of the two terms
+    history = []
+    for epoch in range(start_epoch, n_epochs):
+        lr = lr_schedule(lr0, epoch, lr_exp_decay)
+        tot = torch.zeros(3, dtype=torch.float64)
+        nb = 0
+        for spec_in, emb, spec_out in train_batches(epoch):
+            trainer.step(spec_in, emb, spec_out, lr=lr)
+            tot += eng.loss_out[:3].double().cpu()          # total data loss, amplitude term, phase term of this step
+            nb += 1
+        rec = {"epoch": epoch + 1, "lr": lr, "train_loss": float(tot[0]) / max(nb, 1), "train_amp": float(tot[1]) * inv / max(nb, 1),
+               "train_phase": float(tot[2]) * inv / max(nb, 1)}
+        if val_batches is not None:
+            vt = torch.zeros(3, dtype=torch.float64)
+            vb = 0
+            saved_moving = {k: v.clone() for k, v in eng.moving.items()}
+            for spec_in, emb, spec_out in val_batches(epoch):
+                eng.training = True
+                mask = eng.make_dropout_mask() if trainer.dropout else None
+                eng.forward(spec_in, emb, dropout_mask=mask, target=spec_out, global_batch=eng.B * trainer.world_size, alpha=trainer.alpha)
+                vt += eng.loss_out[:3].double().cpu()
+                vb += 1
+            for k, v in saved_moving.items():                # a forward in training mode moved the BN averages: undo
+                eng.moving[k].copy_(v)
+            rec.update(val_loss=float(vt[0]) / max(vb, 1), val_amp=float(vt[1]) * inv / max(vb, 1), val_phase=float(vt[2]) * inv / max(vb, 1))
+        if manager is not None and epoch % 2 == 0:
+            rec["checkpoint"] = manager.save(epoch=epoch)
+        history.append(rec)
+        if log is not None:
+            log(rec)
+    return history
