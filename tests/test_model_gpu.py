@@ -351,3 +351,32 @@ def test_checkpoint_resume_and_epoch_loop(U, tmp_path):
     assert abs(hist[0]["train_loss"] - (0.9 * hist[0]["train_amp"] + 0.1 * hist[0]["train_phase"])) < 1e-5
     assert torch.equal(eng2.theta, before)                         # lr 0: nothing moved, validation updates nothing
     assert U.lr_schedule(1e-3, 79) == 1e-3 and abs(U.lr_schedule(1e-3, 80) - 1e-3 * 0.9) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_batch_pipeline(U):
+    """datageneratorv2.py:64-102 triples (NHWC float32, int32 indices) arrive on the device as the engine's NCHW inputs,
+    in order and bit-exact, through pinned double-buffered copies on a side stream; generator errors surface."""
+    rng = np.random.default_rng(3)
+    batches = [(rng.random((2, 32, 48, 2), dtype=np.float32), rng.integers(26, 1282, (2, 2, 16)).astype(np.int32),
+                rng.random((2, 32, 48, 2), dtype=np.float32)) for _ in range(5)]
+    got = list(U.DeviceBatchPipeline(iter(batches), DEV, depth=2))
+    assert len(got) == 5
+    for (a, e, b), (da, de, db) in zip(batches, got):
+        assert da.shape == (2, 2, 32, 48) and da.is_contiguous() and da.device.type == "cuda"
+        assert torch.equal(da.cpu(), torch.from_numpy(a).permute(0, 3, 1, 2)) and torch.equal(db.cpu(), torch.from_numpy(b).permute(0, 3, 1, 2))
+        assert torch.equal(de.cpu(), torch.from_numpy(e))
+
+    def bad():
+        yield batches[0]
+        raise RuntimeError("generator failed")
+    with pytest.raises(RuntimeError, match="generator failed"):
+        list(U.DeviceBatchPipeline(bad(), DEV))
+    # the pipeline feeds a train step
+    eng = U.UNetEngine(32, 48, 2, F0=8, dtype="bf16", device=DEV)
+    tr = U.Trainer(eng, lr=1e-3, dropout=False)
+    for spec_in, emb, spec_out in U.DeviceBatchPipeline(iter(batches[:2]), DEV):
+        loss = tr.step(spec_in, emb, spec_out, return_loss=True)
+    assert np.isfinite(loss)
+    s_in, s_emb, s_out = next(U.synthetic_batches(1, 2, 32, 32, DEV))
+    assert float(s_in[:, :, 29:, :].abs().max()) == 0.0 and float(s_in[:, :, :, 31:].abs().max()) == 0.0 and int(s_emb.min()) >= 26

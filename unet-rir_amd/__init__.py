@@ -9,6 +9,7 @@ from .engine import UNetEngine  # noqa: F401
 from .model import UNet  # noqa: F401
 from .resae import ResAEEngine  # noqa: F401
 from .unet_graph import UNetGraphEngine  # noqa: F401
+from .data import DeviceBatchPipeline, synthetic_batches  # noqa: F401
 from .trainer import CheckpointManager, GradBucketer, Trainer, fit, lr_schedule  # noqa: F401
 
-__all__ = ["ops", "build", "UnetrirError", "UNetEngine", "UNetGraphEngine", "ResAEEngine", "UNet", "Trainer", "GradBucketer", "lr_schedule", "CheckpointManager", "fit"]
+__all__ = ["ops", "build", "UnetrirError", "UNetEngine", "UNetGraphEngine", "ResAEEngine", "UNet", "Trainer", "GradBucketer", "lr_schedule", "CheckpointManager", "fit", "DeviceBatchPipeline", "synthetic_batches"]

@@ -1,0 +1,91 @@
+"""Input side of the train step: what `DataGenerator.__getitem__` (datageneratorv2.py:64-102) hands to the model, brought
+onto the device without stalling the step.
+
+The reference generator returns per batch `(spectrogram_in f32 [B,H,W,2], embedding i32 [B,2,16], spectrogram_out f32
+[B,H,W,2])` built in Python on the host.  `DeviceBatchPipeline` wraps any iterable yielding such triples (NumPy arrays or
+CPU tensors, NHWC as the reference or already NCHW): a background thread stages the next batches in pinned host memory and
+copies them on a dedicated HIP stream while the current step runs; the consumer only waits on an event.  The engine's
+boundary is contiguous NCHW fp32 `[B,2,H,W]` (+ the index tensor), so NHWC batches are permuted on the copy stream.
+`synthetic_batches` is the device-side generator SURVEY.md §8(d) specifies for benchmarks.
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+
+class DeviceBatchPipeline:
+    """for spec_in, emb, spec_out in DeviceBatchPipeline(generator, device): trainer.step(spec_in, emb, spec_out)"""
+
+    def __init__(self, source, device, depth=2, nhwc=True):
+        self.source, self.device, self.depth, self.nhwc = source, torch.device(device), max(1, depth), nhwc
+
+    def _to_pinned(self, a, slot, k):
+        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a.contiguous()
+        buf = slot.get(k)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            slot[k] = buf
+        buf.copy_(t)
+        return buf
+
+    def __iter__(self):
+        stream = torch.cuda.Stream(device=self.device)
+        q = queue.Queue(maxsize=self.depth)
+        slots = [dict() for _ in range(self.depth + 1)]        # pinned staging buffers, reused round-robin
+        free = [threading.Semaphore(1) for _ in slots]
+        stop = object()
+
+        def producer():
+            try:
+                for i, (spec_in, emb, spec_out) in enumerate(self.source):
+                    s = i % len(slots)
+                    free[s].acquire()                          # the copy that last used this slot has been consumed
+                    host = [self._to_pinned(spec_in, slots[s], "in"), self._to_pinned(emb, slots[s], "emb"),
+                            self._to_pinned(spec_out, slots[s], "out")]
+                    with torch.cuda.stream(stream):
+                        dev = [h.to(self.device, non_blocking=True) for h in host]
+                        if self.nhwc:                          # [B,H,W,2] -> contiguous [B,2,H,W]
+                            dev[0] = dev[0].permute(0, 3, 1, 2).contiguous()
+                            dev[2] = dev[2].permute(0, 3, 1, 2).contiguous()
+                        dev[0], dev[2] = dev[0].float(), dev[2].float()
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                    q.put((dev, ev, s))
+                q.put(stop)
+            except BaseException as e:                         # surface generator errors in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is stop:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            dev, ev, s = item
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            for t in dev:
+                t.record_stream(torch.cuda.current_stream(self.device))
+            ev.synchronize()                                   # host copy finished: the pinned slot may be refilled
+            free[s].release()
+            yield dev[0], dev[1], dev[2]
+        th.join()
+
+
+def synthetic_batches(n, B, H, W, device, seed=1234, rank=0):
+    """amplitude and phase ~ U[0,1) with the zero padding of the 129/144 x 151/160 STFT core (rows >=
+    ceil(0.896 H), columns >= ceil(0.944 W) exactly 0), indices ~ randint[26, 1282); generated on the device, NCHW."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + rank)
+    r0, c0 = int(np.ceil(0.896 * H)), int(np.ceil(0.944 * W))
+    for _ in range(n):
+        spec_in = torch.rand((B, 2, H, W), device=device, generator=g)
+        spec_out = torch.rand((B, 2, H, W), device=device, generator=g)
+        for s in (spec_in, spec_out):
+            s[:, :, r0:, :] = 0.0
+            s[:, :, :, c0:] = 0.0
+        emb = torch.randint(26, 1282, (B, 2, 16), device=device, generator=g, dtype=torch.int64)
+        yield spec_in, emb, spec_out
