@@ -10,6 +10,7 @@
 // reading the patch at offset (-(kh>>1), -(kw>>1)).  Each wave keeps 4 classes x 2 row sub-tiles (128 accumulator regs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,13 +40,21 @@ __device__ __forceinline__ void umma(f32x16& acc, const uint4& a, const uint4& b
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), acc, 0, 0, 0);
 }
 
-template <typename T>
+// CHUNKED (bf16): a 32-channel chunk (64-byte rows, 80-byte LDS stride) keeps the weights of ALL 9 taps in LDS, so a chunk
+// costs two barriers instead of nine and a patch fragment (2 rows x 2 row offsets x 2 column offsets) is read once for
+// the 9 taps: 17 fragment reads per 18 MFMAs instead of 12 per 8, 36 MFMAs per wave between barriers instead of 8.
+template <typename T, bool CHUNKED = false>
 __global__ __launch_bounds__(512) void upconv3x3_kernel(const Conv3Args a) {
-    constexpr int KE = UElem<T>::KE, EPS = UElem<T>::EPS;
-    constexpr int AJ = (UNP * 8 + 511) / 512;        // patch slots per thread (5)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[UNP * RSB + 2 * UBN * RSB];
+    constexpr int KE = CHUNKED ? 32 : UElem<T>::KE, EPS = UElem<T>::EPS;
+    constexpr int RS = CHUNKED ? 80 : RSB;            // LDS row stride, bytes
+    constexpr int SLOTS = KE / EPS;                   // 16-byte slots per row (4 chunked, 8 otherwise)
+    constexpr int AJ = (UNP * SLOTS + 511) / 512;     // patch slots per thread
+    constexpr int BJ = CHUNKED ? (9 * UBN * SLOTS + 511) / 512 : 1;
+    constexpr int SMEM_MAIN = CHUNKED ? UNP * RS + 9 * UBN * RS : UNP * RSB + 2 * UBN * RSB;
+    constexpr int SMEM_EPI = 8 * 64 * (32 * 2 + 16);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_MAIN > SMEM_EPI ? SMEM_MAIN : SMEM_EPI];
     unsigned char* As = smem;
-    unsigned char* Bs = smem + UNP * RSB;
+    unsigned char* Bs = smem + UNP * RS;
 
     const T* __restrict__ in = (const T*)a.in;
     const T* __restrict__ w = (const T*)a.w;
@@ -66,14 +75,15 @@ __global__ __launch_bounds__(512) void upconv3x3_kernel(const Conv3Args a) {
     const int C = a.C;
     const int nchunks = (C + KE - 1) / KE;
     const int ldw = 9 * C;
-    const int q = tid & 7;
+    const int q = tid & (SLOTS - 1);
+    constexpr int SL = CHUNKED ? 2 : 3;               // log2(SLOTS)
 
     uint4 ra[AJ], rb;
     auto load_a = [&](int c0) {
         const bool cok = (c0 + q * EPS) < C;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int p = (tid + 512 * j) >> 3;
+            const int p = (tid + 512 * j) >> SL;
             const int pr = p / UPC, pc = p - pr * UPC;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -85,8 +95,28 @@ __global__ __launch_bounds__(512) void upconv3x3_kernel(const Conv3Args a) {
     auto store_a = [&]() {
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int p = (tid + 512 * j) >> 3;
-            if (p < UNP) *reinterpret_cast<uint4*>(As + p * RSB + q * 16) = ra[j];
+            const int p = (tid + 512 * j) >> SL;
+            if (p < UNP) *reinterpret_cast<uint4*>(As + p * RS + q * 16) = ra[j];
+        }
+    };
+    // chunked: all 9 taps of the chunk, row = tap * 64 + channel
+    uint4 rbc[BJ];
+    auto load_bc = [&](int c0) {
+        const bool cok = (c0 + q * EPS) < C;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = (tid + 512 * j) >> SL;
+            const int t = row >> 6, n = n0 + (row & 63);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < 9 * UBN && cok && n < a.N) v = *reinterpret_cast<const uint4*>(w + (size_t)n * ldw + t * C + c0 + q * EPS);
+            rbc[j] = v;
+        }
+    };
+    auto store_bc = [&]() {
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            const int row = (tid + 512 * j) >> SL;
+            if (row < 9 * UBN) *reinterpret_cast<uint4*>(Bs + row * RS + q * 16) = rbc[j];
         }
     };
     auto load_b = [&](int step) {                      // 64 rows x 8 slots = 512 slots: one per thread
@@ -106,46 +136,87 @@ __global__ __launch_bounds__(512) void upconv3x3_kernel(const Conv3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
-    load_a(0);
-    load_b(0);
-    store_a();
-    store_b(0);
-    __syncthreads();
-    load_b(1);
-
-    // patch pixel of coarse (row 2wm+i, col l31) at tap offset (-(kh>>1), -(kw>>1)): ((2wm+i+1-(kh>>1)) * UPC + l31+1-(kw>>1))
-    const int a_lane = ((2 * wm + 1) * UPC + l31 + 1) * RSB + hb;
-    const int b_lane = (wn * 32 + l31) * RSB + hb;
-    const int nsteps = nchunks * 9;
-    int step = 0;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) load_a((ch + 1) * KE);
+    if constexpr (CHUNKED) {
+        load_a(0);
+        load_bc(0);
+        store_a();
+        store_bc();
+        __syncthreads();
+        const int a_lane = ((2 * wm + 1) * UPC + l31 + 1) * RS + hb;
+        const int b_lane = (wn * 32 + l31) * RS + hb;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const bool more = ch + 1 < nchunks;
+            if (more) { load_a((ch + 1) * KE); load_bc((ch + 1) * KE); }
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 fa[2][2][2];                         // [row sub-tile][row offset kh>>1][column offset kw>>1]
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw, ++step) {
-                if (step + 1 < nsteps) store_b((step + 1) & 1);
-                if (step + 2 < nsteps) load_b(step + 2);
-                const int cls = (kh & 1) * 2 + (kw & 1);
-                const unsigned char* Ab = As + a_lane - ((kh >> 1) * UPC + (kw >> 1)) * RSB;
-                const unsigned char* Bb = Bs + (step & 1) * (UBN * RSB) + b_lane;
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const uint4 fb = *reinterpret_cast<const uint4*>(Bb + kk * 32);
+                    for (int dr = 0; dr < 2; ++dr)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const uint4 fa = *reinterpret_cast<const uint4*>(Ab + i * (UPC * RSB) + kk * 32);
-                        umma(acc[cls][i], fa, fb, T());
+                        for (int dc = 0; dc < 2; ++dc)
+                            fa[i][dr][dc] = *reinterpret_cast<const uint4*>(As + a_lane + ((i - dr) * UPC - dc) * RS + kk * 32);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const uint4 fb = *reinterpret_cast<const uint4*>(Bs + b_lane + (kh * 3 + kw) * (UBN * RS) + kk * 32);
+                        const int cls = (kh & 1) * 2 + (kw & 1);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) umma(acc[cls][i], fa[i][kh >> 1][kw >> 1], fb, T());
                     }
-                }
+            }
+            __syncthreads();
+            if (more) {
+                store_a();
+                store_bc();
                 __syncthreads();
             }
         }
-        if (ch + 1 < nchunks) {
-            store_a();
-            __syncthreads();
+    } else {
+    load_a(0);
+        load_b(0);
+        store_a();
+        store_b(0);
+        __syncthreads();
+        load_b(1);
+    
+        // patch pixel of coarse (row 2wm+i, col l31) at tap offset (-(kh>>1), -(kw>>1)): ((2wm+i+1-(kh>>1)) * UPC + l31+1-(kw>>1))
+        const int a_lane = ((2 * wm + 1) * UPC + l31 + 1) * RSB + hb;
+        const int b_lane = (wn * 32 + l31) * RSB + hb;
+        const int nsteps = nchunks * 9;
+        int step = 0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch + 1 < nchunks) load_a((ch + 1) * KE);
+    #pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+    #pragma unroll
+                for (int kw = 0; kw < 3; ++kw, ++step) {
+                    if (step + 1 < nsteps) store_b((step + 1) & 1);
+                    if (step + 2 < nsteps) load_b(step + 2);
+                    const int cls = (kh & 1) * 2 + (kw & 1);
+                    const unsigned char* Ab = As + a_lane - ((kh >> 1) * UPC + (kw >> 1)) * RSB;
+                    const unsigned char* Bb = Bs + (step & 1) * (UBN * RSB) + b_lane;
+    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const uint4 fb = *reinterpret_cast<const uint4*>(Bb + kk * 32);
+    #pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const uint4 fa = *reinterpret_cast<const uint4*>(Ab + i * (UPC * RSB) + kk * 32);
+                            umma(acc[cls][i], fa, fb, T());
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (ch + 1 < nchunks) {
+                store_a();
+                __syncthreads();
+            }
         }
-    }
+    
+}
 
     const int OH = 2 * a.H, OW = 2 * a.W;
     T* __restrict__ out = (T*)a.out;
@@ -231,7 +302,9 @@ __global__ __launch_bounds__(512) void upconv3x3_kernel(const Conv3Args a) {
 
 int launch_upconv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + UR - 1) / UR) * ((a.W + UC - 1) / UC) * ((a.N + UBN - 1) / UBN);
-    if (bf16) hipLaunchKernelGGL(upconv3x3_kernel<__bf16>, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    static const bool chunked = [] { const char* e = getenv("UNETRIR_UPCONV_CHUNKED"); return !(e && e[0] == '0'); }();
+    if (bf16 && chunked) hipLaunchKernelGGL((upconv3x3_kernel<__bf16, true>), dim3((unsigned)tiles), dim3(512), 0, s, a);
+    else if (bf16) hipLaunchKernelGGL(upconv3x3_kernel<__bf16>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(upconv3x3_kernel<float>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     return (int)hipGetLastError();
 }
