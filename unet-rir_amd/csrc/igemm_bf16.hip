@@ -489,8 +489,10 @@ void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit
 #define TPH_S2 4
 
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (stride == 1) {       // patch rows reused from registers (wgrad3x3r.hip)
-        const int err = launch_wgrad3x3r_bf16(a, dw, reg, w, ws, ws_bytes, s);
+    if (stride == 1) {       // patch rows reused from registers: LDS-DMA staged (wgrad3x3g.hip), else register staged (wgrad3x3r.hip)
+        int err = launch_wgrad3x3g_bf16(a, dw, reg, w, ws, ws_bytes, s);
+        if (err != WGRAD3X3R_NOT_TAKEN) return err;
+        err = launch_wgrad3x3r_bf16(a, dw, reg, w, ws, ws_bytes, s);
         if (err != WGRAD3X3R_NOT_TAKEN) return err;
     }
     int ns, per;

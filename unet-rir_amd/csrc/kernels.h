@@ -80,6 +80,7 @@ int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
 int launch_igemm_fwd_bf16_x4(const IgemmArgsH* a, hipStream_t s);
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 #define WGRAD3X3R_NOT_TAKEN (-12345)
+int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_wgrad3x3r_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 int launch_cast_weight(const float* w, void* o, int N, int T, int C, int Cp, hipStream_t s);
 int launch_cast_weights_batched(const unetrir_cast_desc* desc_dev, int n_layers, hipStream_t s);

@@ -1,0 +1,236 @@
+// wgrad3x3g.hip - bf16 weight gradient of the 3x3 stride-1 convolution: wgrad3x3r.hip's register reuse of patch rows with
+// LDS-DMA staging.
+//
+// dW[n][kh][kw][c] = sum_p dy[p][n] * x[p + (kh-1, kw-1)][c].  A workgroup (4 waves, each a 32 x 32 (n, c) tile for all 9
+// taps) owns a 64 x 64 (n, c) tile and a split-K slice of 8 x 16 pixel patches.  The x patch (10 x 18 pixels x 64 channels)
+// and the dy patch (8 x 16 x 64) of the NEXT patch are requested with buffer_load_dwordx4 ... lds while the current one is
+// being multiplied (two LDS buffers, one raw s_barrier per patch, no staging registers, no ds_write); out-of-image pixels
+// and channel tails are buffer offsets past num_records and read zeros.  LDS rows are unpadded 128-byte pixels; the
+// transposed fragment reads (ds_read_b64_tr_b16, 4 consecutive pixels x 64 B per 32-lane half) stay conflict-free because
+// the two 64-byte halves of a pixel row are swapped where bit 1 of the pixel's column is set - applied to the DMA source
+// granule and to the read address.  Fragment reads are inline asm (the compiler would wait for the outstanding DMA
+// before any LDS read it can see) and are issued one K step ahead of the MFMAs that consume them.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define TRR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM0() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+namespace {
+constexpr int WTPH = 8, WTPW = 16;
+constexpr int WXH = WTPH + 2, WXW = WTPW + 2;          // 10 x 18 x-patch pixels
+constexpr int WX_INSTR = (WXH * WXW + 7) / 8;          // 23 wave-instructions of 8 pixels x 128 B
+constexpr int WD_INSTR = WTPH * WTPW / 8;              // 16
+constexpr int WX_BYTES = WX_INSTR * 1024, WD_BYTES = WD_INSTR * 1024;
+constexpr int WBUF = WX_BYTES + WD_BYTES;              // 39936
+constexpr uint32_t WOOB = 0xF0000000u;
+
+__device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
+    u32x4 v; v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(bf16x8, v);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WBUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int ntC = (a.C + 63) / 64;
+    const int rt = blockIdx.x / ntC, ct = blockIdx.x - rt * ntC;
+    const int n0 = rt * 64, c0 = ct * 64;
+    const int per_img = a.npy * a.npx;
+    const int G = a.B * per_img;
+    const int g0 = blockIdx.y * a.patches_per_split;
+    int g1 = g0 + a.patches_per_split;
+    if (g1 > G) g1 = G;
+
+    // ---- DMA lane constants: instruction i covers patch pixels 8i .. 8i+7, lane = (pixel sub, 16-byte granule g8)
+    const int g8 = lane & 7, sub = lane >> 3;
+    int xpr[6], xpc[6];
+    uint32_t xrel[6];
+    bool xcok[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        int i = wave + 4 * j;
+        if (i > WX_INSTR - 1) i = WX_INSTR - 1;
+        const int p = 8 * i + sub;
+        const int pr = p / WXW, pc = p - pr * WXW;
+        const int gs = g8 ^ (((pc >> 1) & 1) << 2);
+        xpr[j] = p < WXH * WXW ? pr : 1 << 20;          // pixels past the patch: never valid
+        xpc[j] = pc;
+        xrel[j] = (uint32_t)(((pr * a.IW + pc) * a.ldx + gs * 8) * 2);
+        xcok[j] = (c0 + gs * 8) < a.C;
+    }
+    int dr_[4], dc_[4];
+    uint32_t drel[4];
+    bool dnok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 8 * (wave + 4 * j) + sub;
+        const int oyl = p >> 4, oxl = p & 15;
+        const int gs = g8 ^ (((oxl >> 1) & 1) << 2);
+        dr_[j] = oyl; dc_[j] = oxl;
+        drel[j] = (uint32_t)(((oyl * a.OW + oxl) * a.lddy + gs * 8) * 2);
+        dnok[j] = (n0 + gs * 8) < a.N;
+    }
+    const size_t x_img = (size_t)a.IH * a.IW * a.ldx, d_img = (size_t)a.OH * a.OW * a.lddy;
+    const int x_rec = (int)((((size_t)a.IH * a.IW - 1) * a.ldx + a.C) * 2), d_rec = (int)((((size_t)a.OH * a.OW - 1) * a.lddy + a.N) * 2);
+
+    auto issue = [&](int g, int buf) {
+        const int img = g / per_img;
+        const int rem = g - img * per_img;
+        const int pyi = rem / a.npx, pxi = rem - pyi * a.npx;
+        const int py0 = pyi * WTPH, px0 = pxi * WTPW;
+        const int iy0 = py0 - a.pad_t, ix0 = px0 - a.pad_l;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + img * x_img), (short)0, x_rec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + img * d_img), (short)0, d_rec, 0x00020000);
+        unsigned char* xb = smem + buf * WBUF;
+        unsigned char* db = xb + WX_BYTES;
+        const int xbase = ((iy0 * a.IW + ix0) * a.ldx + c0) * 2;       // may be negative; only used for valid pixels
+        const int dbase = ((py0 * a.OW + px0) * a.lddy + n0) * 2;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            int i = wave + 4 * j;
+            if (i > WX_INSTR - 1) i = WX_INSTR - 1;
+            const int iy = iy0 + xpr[j], ix = ix0 + xpc[j];
+            const bool ok = xcok[j] && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+            const uint32_t off = ok ? (uint32_t)(xbase + (int)xrel[j]) : WOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xb + i * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = dnok[j] && (py0 + dr_[j]) < a.OH && (px0 + dc_[j]) < a.OW;
+            const uint32_t off = ok ? (uint32_t)(dbase + (int)drel[j]) : WOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lptr_t)(db + (wave + 4 * j) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- fragment read addresses (ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies pixel row q, channels 4p..4p+3;
+    // groups 0/1 = channels 0-15/16-31 of pixels 0-7 of the 16-pixel K step, groups 2/3 of pixels 8-15)
+    const int grp = lane >> 4, li = lane & 15;
+    const int tq = li >> 2, tp = li & 3;
+    const int lane_px = 8 * h + tq;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    uint32_t xoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        xoff[m] = lane_px * 128 + ((wc * 64 + (grp & 1) * 32 + tp * 8) ^ ((((lane_px + m) >> 1) & 1) << 6));
+    const uint32_t doff = lane_px * 128 + ((wr * 64 + (grp & 1) * 32 + tp * 8) ^ (((lane_px >> 1) & 1) << 6));
+
+    // x fragment of patch row R, column shift kw: two reads (pixels +0..3 and +4..7 of this lane's group)
+#define RDX(lo, hi, R, KW) do { TRR(lo, xa[(KW) & 3], (R) * (WXW * 128) + (KW) * 128); \
+                                TRR(hi, xa[((KW) + 4) & 3], (R) * (WXW * 128) + ((KW) + 4) * 128); } while (0)
+#define RDD(lo, hi, R) do { TRR(lo, da, (R) * (WTPW * 128)); TRR(hi, da, (R) * (WTPW * 128) + 4 * 128); } while (0)
+#define MM(T_, A_, B_) acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[T_], 0, 0, 0)
+    // one K step: dy row R against x rows R (kh 0), R+1, R+2.  S0 = ring slot of x row R (refilled with row R+3 once the
+    // kh = 0 products are issued), S1, S2 = slots of rows R+1, R+2.
+#define STEP(R, S0, S1, S2, DC_LO, DC_HI, DN_LO, DN_HI, MORE)                                                     \
+    do {                                                                                                            \
+        LGKM0();                                                                                                    \
+        const bf16x8 fd = frag(DC_LO, DC_HI);                                                                       \
+        MM(0, fd, frag(xl[S0][0], xh[S0][0])); MM(1, fd, frag(xl[S0][1], xh[S0][1])); MM(2, fd, frag(xl[S0][2], xh[S0][2])); \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (MORE) {                                                                                                 \
+            RDX(xl[S0][0], xh[S0][0], (R) + 3, 0); RDX(xl[S0][1], xh[S0][1], (R) + 3, 1); RDX(xl[S0][2], xh[S0][2], (R) + 3, 2); \
+            RDD(DN_LO, DN_HI, (R) + 1);                                                                             \
+        }                                                                                                           \
+        MM(3, fd, frag(xl[S1][0], xh[S1][0])); MM(4, fd, frag(xl[S1][1], xh[S1][1])); MM(5, fd, frag(xl[S1][2], xh[S1][2])); \
+        MM(6, fd, frag(xl[S2][0], xh[S2][0])); MM(7, fd, frag(xl[S2][1], xh[S2][1])); MM(8, fd, frag(xl[S2][2], xh[S2][2])); \
+    } while (0)
+
+    if (g0 < g1) issue(g0, 0);
+    int k = 0;
+    for (int g = g0; g < g1; ++g, k ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of patch g has landed ...
+        __builtin_amdgcn_s_barrier();                            // ... everybody's has; everybody is done reading the other buffer
+        asm volatile("" ::: "memory");
+        if (g + 1 < g1) issue(g + 1, k ^ 1);
+        const uint32_t xb = lds0 + k * WBUF, db = xb + WX_BYTES;
+        uint32_t xa[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xa[m] = xb + xoff[m];
+        const uint32_t da = db + doff;
+        u32x2 xl[3][3], xh[3][3], d0l, d0h, d1l, d1h;
+        RDX(xl[0][0], xh[0][0], 0, 0); RDX(xl[0][1], xh[0][1], 0, 1); RDX(xl[0][2], xh[0][2], 0, 2);
+        RDX(xl[1][0], xh[1][0], 1, 0); RDX(xl[1][1], xh[1][1], 1, 1); RDX(xl[1][2], xh[1][2], 1, 2);
+        RDX(xl[2][0], xh[2][0], 2, 0); RDX(xl[2][1], xh[2][1], 2, 1); RDX(xl[2][2], xh[2][2], 2, 2);
+        RDD(d0l, d0h, 0);
+        STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true);
+        STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true);
+        STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true);
+        STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true);
+        STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true);
+        STEP(5, 2, 0, 1, d1l, d1h, d0l, d0h, true);
+        STEP(6, 0, 1, 2, d0l, d0h, d1l, d1h, true);
+        // last step: x row 10 does not exist; nothing left to prefetch
+        STEP(7, 1, 2, 0, d1l, d1h, d0l, d0h, false);
+    }
+#undef STEP
+#undef MM
+#undef RDD
+#undef RDX
+
+    float* part = a.part + (size_t)blockIdx.y * a.N * 9 * a.C;
+    const int c = c0 + wc * 32 + (lane & 31);
+    if (c < a.C) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < a.N) part[((size_t)n * 9 + t) * a.C + c] = acc[t][r];
+            }
+    }
+}
+
+static void plan_g(int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx) {
+    static const long long target = [] { const char* e = getenv("UNETRIR_WG_TARGET"); return e ? atoll(e) : 512ll; }();
+    *npy = (OH + WTPH - 1) / WTPH;
+    *npx = (OW + WTPW - 1) / WTPW;
+    const long long G = (long long)B * (*npy) * (*npx);
+    const long long tiles = (long long)((N + 63) / 64) * ((C + 63) / 64);
+    long long want = (target + tiles - 1) / tiles;
+    long long maxs = (G + 3) / 4;
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    const long long per = (G + want - 1) / want;
+    *per_split = (int)per;
+    *nsplit = (int)((G + per - 1) / per);
+}
+
+// stride-1 3x3 weight gradient; WGRAD3X3R_NOT_TAKEN when this kernel does not take the layer (the caller falls back)
+int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    static const bool on = [] { const char* e = getenv("UNETRIR_WGRAD3X3G"); return !(e && e[0] == '0'); }();
+    const size_t x_bytes = (((size_t)a.IH * a.IW - 1) * a.ldx + a.C) * 2, d_bytes = (((size_t)a.OH * a.OW - 1) * a.lddy + a.N) * 2;
+    if (!on || a.OH % 8 != 0 || x_bytes >= 0x70000000u || d_bytes >= 0x70000000u || (a.C & 7) || (a.N & 7)) return WGRAD3X3R_NOT_TAKEN;
+    int ns, per;
+    plan_g(a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    const size_t nout = (size_t)a.N * 9 * a.C;
+    const bool direct = (ns == 1 && reg == 0.f);
+    if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return WGRAD3X3R_NOT_TAKEN;
+    a.part = direct ? dw : (float*)ws;
+    a.patches_per_split = per;
+    const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
+    hipLaunchKernelGGL(wgrad3x3g_bf16_kernel, dim3(tiles, ns), dim3(256), 0, s, a);
+    const int err = (int)hipGetLastError();
+    if (err || direct) return err;
+    return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);
+}
