@@ -189,6 +189,12 @@ def main():
         return
 
     global_batch = args.batch * world
+    if (args.f0, args.size, args.depth, args.batch) == (64, 256, 4, 32):
+        cfg_name = "BASELINE.json configs[1]"
+    elif (args.f0, args.size, args.depth, args.batch) == (128, 512, 5, 16):
+        cfg_name = "BASELINE.json configs[3]'s model"
+    else:
+        cfg_name = "non-BASELINE shape"
     out = {
         "metric": "RIR spectrograms/sec (train step) on [B,2,256,256] U-Net",
         "value": main_res["value"],
@@ -197,7 +203,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": head_dtype, "data": "synthetic",
         "config": {"workload": f"UNet {args.depth} down/{args.depth} up, number_filters_0={args.f0}, kernels=3, per-GPU batch "
-                               f"{args.batch} of [2,{H},{W}] + [2,16] (BASELINE.json configs[1] per GPU; global batch "
+                               f"{args.batch} of [2,{H},{W}] + [2,16] ({cfg_name} per GPU; global batch "
                                f"{global_batch}), full train step: fwd + loss + bwd + grad all-reduce + Adam; "
                                + ("bf16 activations/gradients, fp32 accumulate/statistics/master weights" if head_dtype == "bf16"
                                   else "fp32 throughout"),
