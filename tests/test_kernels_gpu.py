@@ -319,6 +319,7 @@ BF16_CONV_CASES = [
     (1, 10, 12, 40, 72, 3, 1), (1, 12, 12, 64, 8, 6, 1), (2, 16, 16, 128, 64, 3, 1), (1, 32, 32, 8, 64, 3, 1),
     (2, 24, 70, 48, 160, 3, 1), (1, 40, 64, 136, 64, 3, 1),          # patch-staged kernel: multi-tile, ragged, 3 chunks
     (2, 32, 72, 40, 72, 3, 2),                                        # stride 2: fused parity-class data gradient
+    (1, 32, 64, 24, 64, 3, 2),                                        # stride 2: data gradient on upconv3x3g (C = 64 output channels)
     (2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1),            # LDS-DMA kernel (conv3x3g): ragged tiles / channels, 3 chunks
     (2, 32, 32, 128, 256, 3, 1),                                      # LDS-DMA kernel: forward 4 chunks, data gradient 8 chunks
 ]
@@ -370,7 +371,8 @@ def test_conv2d_bf16(U, case):
 
 
 @pytest.mark.parametrize("case", [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (2, 3, 3, 128, 64, 3), (2, 12, 40, 48, 72, 3),
-                                  (1, 16, 32, 136, 64, 3)])
+                                  (1, 16, 32, 136, 64, 3),
+                                  (1, 16, 64, 96, 72, 3), (2, 20, 32, 32, 64, 3)])   # LDS-DMA kernel (upconv3x3g): 3 chunks / ragged N, ragged rows
 def test_conv2d_transpose_bf16(U, case):
     ops = U.ops
     B, H, W, Ci, Co, k = case

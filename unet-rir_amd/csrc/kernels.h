@@ -106,6 +106,8 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
                            int* nblk_out, hipStream_t s);
 bool head_dgrad_mfma_applies(int W, int C);
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s);
+bool upconv3x3g_applies(const Conv3Args& a);
+int launch_upconv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3g_applies(const Conv3Args& a);
 bool conv3x3_has_colstat(const Conv3Args& a);
 bool conv3x3h_applies(const Conv3Args& a);
