@@ -115,9 +115,10 @@ class UNetEngine:
         self.training = True
         self.t_dirty = True
         # overlap_wgrad: weight gradients depend only on tensors the main stream has already produced, so they can run on a
-        # side HIP stream (own scratch buffer) beside the dgrad -> BatchNorm-backward chain.  Measured +3% in bf16, 0% in
-        # fp32 at cfg 2; off by default because overlapping launches make per-kernel event timing (bench.py roofline)
-        # ill-defined.
+        # side HIP stream (own scratch buffer) beside the dgrad -> BatchNorm-backward chain.  Measured -0.5 ms per step
+        # (3 %) in bf16 at cfg 2 (scripts/overlap_ab.py, alternating engines in one process), 0 % in fp32.  bench.py turns
+        # it on; the default stays off because overlapping launches make per-kernel event brackets (tests, roofline of the
+        # backward kernels) ill-defined.
         self.wg_stream = torch.cuda.Stream(device=self.device) if overlap_wgrad else None
         self.ws_w = ops.Workspace(self.device, self.ws.nbytes) if overlap_wgrad else self.ws
         self.head_direct = ops.head6x6_supported(self.ch[0])
@@ -547,10 +548,21 @@ class UNetEngine:
             ops.sigmoid_bwd(self.pred, dpred, self.g_logits)
 
         def ready(name):
-            if on_ready is not None:
-                self._join_wg()        # the bucket's weight gradients were produced on the side stream
-                s_ = self.specs[name]
-                on_ready(s_.offset + (-(-s_.numel // ALIGN) * ALIGN))
+            if on_ready is None:
+                return
+            s_ = self.specs[name]
+            off = s_.offset + (-(-s_.numel // ALIGN) * ALIGN)
+            if self.wg_stream is None:
+                on_ready(off)
+                return
+            # A bucket's gradients come from both streams (weight gradients: side stream; BatchNorm / fused bias
+            # gradients: main stream).  Let the SIDE stream wait for the main stream's progress and hand the bucket over
+            # from there: the all-reduce orders after both, and the main stream never blocks on the side stream.
+            ev = torch.cuda.Event()
+            ev.record()
+            self.wg_stream.wait_event(ev)
+            with torch.cuda.stream(self.wg_stream):
+                on_ready(off)
 
         gl = self.g_logits
         if self.head_direct:
