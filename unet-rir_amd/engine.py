@@ -44,6 +44,48 @@ class ParamSpec:
         self.offset = -1
 
 
+def pick_concurrent_streams(device, n, candidates=12):
+    """n HIP streams that really run beside the current stream and beside each other.  Streams are multiplexed onto a few
+    hardware queues, and two streams that share a queue execute in order: the side-stream schedule then gains nothing (or
+    loses: measured 14.1 vs 15.0-17.3 ms per step depending on which pool streams an engine happened to get).  So probe:
+    queue ~2 ms of copies on stream A, then a tiny kernel on candidate B; B is concurrent with A if its kernel finishes
+    while A is still busy."""
+    dev = torch.device(device)
+    main = torch.cuda.current_stream(dev)
+    a = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    tiny = torch.zeros(64, device=dev)
+
+    def runs_beside(busy, cand):
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(busy):
+            for _ in range(24):
+                b.copy_(a, non_blocking=True)
+            end_busy = torch.cuda.Event()
+            end_busy.record(busy)
+        with torch.cuda.stream(cand):
+            tiny.add_(1.0)
+            end_cand = torch.cuda.Event()
+            end_cand.record(cand)
+        end_cand.synchronize()
+        ok = not end_busy.query()
+        torch.cuda.synchronize(dev)
+        return ok
+
+    chosen, pool = [], [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    for c in pool:
+        if len(chosen) == n:
+            break
+        if all(runs_beside(o, c) and runs_beside(c, o) for o in [main] + chosen):
+            chosen.append(c)
+    for c in pool:                      # fewer independent queues than asked for: fill up (correct, just less overlap)
+        if len(chosen) == n:
+            break
+        if c not in chosen:
+            chosen.append(c)
+    return chosen
+
+
 class _SideStream:
     """`with engine._wg() as ws:` - enqueue on the weight-gradient stream after everything the main stream has queued."""
 
@@ -119,7 +161,8 @@ class UNetEngine:
         # (3 %) in bf16 at cfg 2 (scripts/overlap_ab.py, alternating engines in one process), 0 % in fp32.  bench.py turns
         # it on; the default stays off because overlapping launches make per-kernel event brackets (tests, roofline of the
         # backward kernels) ill-defined.
-        self.wg_stream = torch.cuda.Stream(device=self.device) if overlap_wgrad else None
+        # two probed streams: weight gradients, and the trainer's bucket-wise optimizer (trainer.py)
+        self.wg_stream, self.opt_stream = pick_concurrent_streams(self.device, 2) if overlap_wgrad else (None, None)
         self.ws_w = ops.Workspace(self.device, self.ws.nbytes) if overlap_wgrad else self.ws
         self.head_direct = ops.head6x6_supported(self.ch[0])
         if self.head_direct:
@@ -487,25 +530,39 @@ class UNetEngine:
         if self.t_dirty or self.training:
             self.refresh_transposed()
         self.emb_idx.copy_(emb.reshape(-1).to(torch.int32))
+        self.dropout_mask = dropout_mask
+
+        def vec_branch(ws_):
+            """information vector branch (dl_models/u_net.py:253-263) up to (bf16: including) its 1x1 conv"""
+            ops.embedding_fwd(self.emb_idx, p["vec.embedding"], self.emb_out)
+            ops.dense_fwd(self.flat, p["vec.dense.kernel"], p["vec.dense.bias"], self.v, ws_)
+            if dropout_mask is not None:
+                ops.mul(self.v.base, dropout_mask, self.vd.base)
+                vsp_ = self.vd_sp
+            else:
+                vsp_ = Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
+            if self.dtype != "f32":   # the branch is fp32; its 1x1 conv output joins the bf16 trunk through the Add()
+                ops.conv2d_fwd(self.geo["vec.conv"], vsp_, p["vec.conv.kernel"], p["vec.conv.bias"], self.v1x1)
+            return vsp_
+
+        vsp = None
+        if self.wg_stream is not None:      # independent of the encoder until the Add(): side stream, joined below
+            with self._wg() as ws_:
+                vsp = vec_branch(ws_)
         ops.nchw_to_nhwc_pad(spec, self.x4)
         prev = self.x4
         for l in range(1, self.L + 1):
             ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, self.wf(f"enc{l}.down.kernel"), p[f"enc{l}.down.bias"], self.down[l])
             self._conv_bn_relu_fwd(f"enc{l}.cb1", self.down[l], self.y[l], self.a[l])
             prev = self.a[l]
-        # information vector branch (dl_models/u_net.py:253-263) + Add (:229)
-        ops.embedding_fwd(self.emb_idx, p["vec.embedding"], self.emb_out)
-        ops.dense_fwd(self.flat, p["vec.dense.kernel"], p["vec.dense.bias"], self.v, self.ws)
-        self.dropout_mask = dropout_mask
-        if dropout_mask is not None:
-            ops.mul(self.v.base, dropout_mask, self.vd.base)
-            vsp = self.vd_sp
+        if self.wg_stream is None:
+            vsp = vec_branch(self.ws)
         else:
-            vsp = Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
+            self._join_wg()
+        # Add (dl_models/u_net.py:229)
         if self.dtype == "f32":
             ops.conv2d_fwd(self.geo["vec.conv"], vsp, p["vec.conv.kernel"], p["vec.conv.bias"], self.z, addend=self.a[self.L])
-        else:   # the branch is fp32; its 1x1 conv output joins the bf16 trunk through the Add()
-            ops.conv2d_fwd(self.geo["vec.conv"], vsp, p["vec.conv.kernel"], p["vec.conv.bias"], self.v1x1)
+        else:
             ops.add_f32_to_bf16(self.a[self.L], self.v1x1, self.z)
         cur = self.z
         for l in range(D, 0, -1):
@@ -610,30 +667,27 @@ class UNetEngine:
                     ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
             ready(f"dec{l}.up.bias")
             ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, self.wf(f"dec{l}.up.kernel"), g_in)
-        # bottleneck: z = a_L + conv1x1(dropout(dense(embedding)))
-        gz = self.g_z
-        if self.dtype == "bf16":      # the information-vector branch is fp32: give it an fp32 copy of dL/dz
-            ops.cast_bf16_to_f32(self.g_z, self.g_z32)
-            gz = self.g_z32
+        # bottleneck: z = a_L + conv1x1(dropout(dense(embedding))).  Nothing downstream of the information-vector branch feeds the
+        # encoder's backward chain (that needs only g_z), so the whole branch runs on the weight-gradient stream when there is one.
         B = self.B
         has_do = self.dropout_mask is not None
         vsp = self.vd_sp if has_do else Act(self.v.base.view(B, self.h5, self.w5, VEC_CH))
         with self._wg() as ws_:
+            gz = self.g_z
+            if self.dtype == "bf16":      # the information-vector branch is fp32: give it an fp32 copy of dL/dz
+                ops.cast_bf16_to_f32(self.g_z, self.g_z32)
+                gz = self.g_z32
             ops.conv2d_wgrad(self.geo["vec.conv"], vsp, gz, g["vec.conv.kernel"], ws_)
-        with self._wg() as ws_:
             ops.colsum(gz, g["vec.conv.bias"], ws_)
-        ops.conv2d_dgrad(self.geo["vec.conv"], gz, pt["vec.conv.kernel"], self.g_vd_sp)
-        if has_do:
-            ops.mul(self.g_vd.base, self.dropout_mask, self.g_v.base)
-            gv = self.g_v
-        else:
-            gv = self.g_vd
-        with self._wg() as ws_:
+            ops.conv2d_dgrad(self.geo["vec.conv"], gz, pt["vec.conv.kernel"], self.g_vd_sp)
+            if has_do:
+                ops.mul(self.g_vd.base, self.dropout_mask, self.g_v.base)
+                gv = self.g_v
+            else:
+                gv = self.g_vd
             ops.conv2d_wgrad(self.geo["vec.dense"], self.flat, gv, g["vec.dense.kernel"], ws_)
-        with self._wg() as ws_:
             ops.colsum(gv, g["vec.dense.bias"], ws_)
-        ops.dense_fwd(gv, pt["vec.dense.kernel"], None, self.g_flat, self.ws)      # dL/dflat = dv . W (the [in][out] copy)
-        with self._wg() as ws_:
+            ops.dense_fwd(gv, pt["vec.dense.kernel"], None, self.g_flat, ws_)      # dL/dflat = dv . W (the [in][out] copy)
             ops.embedding_bwd(self.emb_idx, self.g_emb_out, g["vec.embedding"])
         ready("vec.embedding")
         # encoder, deepest level first; the gradient of a_l is (skip half of g_cat_l) + dgrad of the next strided conv
@@ -676,6 +730,17 @@ class UNetEngine:
         t = self.adam_t
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
         ops.adam(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps, grad_scale)
+        self.t_dirty = True
+
+    def adam_begin(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """Advance the step count once and return the arguments of adam_range for this step (bucket-wise optimizer)."""
+        self.adam_t += 1
+        t = self.adam_t
+        return (lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t), beta1, beta2, eps, grad_scale)
+
+    def adam_range(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
+        """Adam on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
+        ops.adam(self.theta[lo:hi], self.grad[lo:hi], self.adam_m[lo:hi], self.adam_v[lo:hi], lr_t, beta1, beta2, eps, grad_scale)
         self.t_dirty = True
 
     def make_dropout_mask(self, generator=None):

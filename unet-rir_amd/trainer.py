@@ -21,10 +21,15 @@ class GradBucketer:
     (SUM) each bucket as soon as the backward pass has produced it.  Device agnostic: the same object drives RCCL
     on GPUs and gloo in the CPU tests."""
 
-    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None):
-        """boundaries: increasing element offsets at which a gradient range [0, off) can become final."""
+    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None, reduce=True, on_bucket=None):
+        """boundaries: increasing element offsets at which a gradient range [0, off) can become final.
+        reduce=False: no collective (single replica), only the bucket schedule.  on_bucket(lo, hi, work) is called for
+        every bucket right after its all-reduce has been launched (work is None without a collective): the hook the
+        trainer uses to start the optimizer on finished buckets while the backward pass is still running."""
         self.flat = flat_grad
         self.group = group
+        self.reduce = reduce
+        self.on_bucket = on_bucket
         self.bounds = []
         last, limit = 0, max(bucket_bytes // 4, 1)
         for off in boundaries:
@@ -51,8 +56,12 @@ class GradBucketer:
         """Everything in [0, offset_end) is final (the launches that write it are enqueued)."""
         while self.next < len(self.bounds) and self.bounds[self.next] <= offset_end:
             hi = self.bounds[self.next]
-            self.works.append(dist.all_reduce(self.flat[self.sent:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+            work = None
+            if self.reduce:
+                work = dist.all_reduce(self.flat[self.sent:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.works.append(work)
+            if self.on_bucket is not None:
+                self.on_bucket(self.sent, hi, work)
             self.sent = hi
             self.next += 1
 
@@ -84,9 +93,16 @@ class Trainer:
         self.bucketer = None
         engine.n_replicas = world_size
         # UNETRIR_FORCE_DP=1 exercises the bucketed all-reduce path on a 1-rank process group (single-GPU rehearsal)
-        if world_size > 1 or (os.environ.get("UNETRIR_FORCE_DP") == "1" and dist.is_initialized()):
+        dp = world_size > 1 or (os.environ.get("UNETRIR_FORCE_DP") == "1" and dist.is_initialized())
+        # With a side stream in the engine (overlap_wgrad) the optimizer also leaves the critical path: Adam runs bucket by
+        # bucket on a third stream as soon as a bucket's gradients are final (and, data-parallel, all-reduced), while the
+        # backward pass continues.  A finished bucket's parameters are never read again by that backward pass.
+        self.adam_stream = getattr(engine, "opt_stream", None) if getattr(engine, "wg_stream", None) is not None else None
+        self._adam_args = None
+        if dp or self.adam_stream is not None:
             bounds = [s_.offset + (-(-s_.numel // ALIGN) * ALIGN) for s_ in engine.specs.values()]
-            self.bucketer = GradBucketer(engine.grad, bounds, bucket_bytes, group)
+            self.bucketer = GradBucketer(engine.grad, bounds, bucket_bytes, group, reduce=dp,
+                                         on_bucket=self._adam_bucket if self.adam_stream is not None else None)
 
     def broadcast_parameters(self, src=0):
         """Replicas start from identical variables (MirroredStrategy mirrors them at creation)."""
@@ -96,6 +112,18 @@ class Trainer:
                 dist.broadcast(b, src=src, group=self.group)
             self.engine.t_dirty = True
 
+    def _adam_bucket(self, lo, hi, work):
+        """Adam on parameters [lo, hi) once everything queued so far on the calling stream (the engine hands buckets over
+        from its side stream, which has waited for the main stream) and the bucket's all-reduce are done."""
+        eng = self.engine
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.adam_stream):
+            self.adam_stream.wait_event(ev)
+            if work is not None:
+                work.wait()
+            eng.adam_range(lo, hi, *self._adam_args)
+
     def step(self, spec_in, emb, spec_out, dropout_mask=None, lr=None, return_loss=False):
         """inputs as DataGenerator.__getitem__ yields them (datageneratorv2.py:101-102), NCHW, per-replica shard."""
         eng = self.engine
@@ -104,15 +132,26 @@ class Trainer:
             dropout_mask = eng.make_dropout_mask()
         gb = eng.B * self.world_size
         eng.forward(spec_in, emb, dropout_mask=dropout_mask, target=spec_out, global_batch=gb, alpha=self.alpha)
-        if self.bucketer is not None:
-            self.bucketer.reset()
-            eng.backward(on_ready=self.bucketer.mark_ready)
-            self.bucketer.finish()
-        else:
-            eng.backward()
         if return_loss:
             eng.reg_loss()                      # on the pre-update weights, as compute_loss sees them
-        eng.adam_step(self.lr if lr is None else lr)
+        lr_now = self.lr if lr is None else lr
+        if self.adam_stream is not None:
+            self._adam_args = eng.adam_begin(lr_now)
+            self.bucketer.reset()
+            eng.backward(on_ready=self.bucketer.mark_ready)
+            self.bucketer.finish()              # hands over the last bucket(s); every all-reduce is waited for on the Adam stream
+            done = torch.cuda.Event()
+            done.record(self.adam_stream)
+            torch.cuda.current_stream().wait_event(done)
+            eng.t_dirty = True
+        else:
+            if self.bucketer is not None:
+                self.bucketer.reset()
+                eng.backward(on_ready=self.bucketer.mark_ready)
+                self.bucketer.finish()
+            else:
+                eng.backward()
+            eng.adam_step(lr_now)
         if return_loss:
             return self.last_loss()
         return None
