@@ -273,6 +273,32 @@ def test_overlapped_weight_gradient_stream_gives_identical_results(U):
     assert torch.equal(grads[0], grads[1])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_overlapped_trainer_schedule_is_bit_identical(U, dtype):
+    """Trainer on an engine with side streams (weight gradients + information-vector branch on one, bucket-wise Adam on
+    another, buckets of a few KB so that several are in flight) against the plain single-stream trainer: same parameters,
+    Adam state, BatchNorm moving statistics and loss after every step, bit for bit."""
+    cfg = R.Config(32, 32, 8, 3)
+    Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, 2)
+    t = lambda a: torch.tensor(a).to(DEV)
+    out = []
+    for ov in (False, True):
+        eng = U.UNetEngine(32, 32, 2, F0=8, device=DEV, dtype=dtype, overlap_wgrad=ov)
+        eng.load_keras_params(Pn)
+        tr = U.Trainer(eng, lr=1e-3, dropout=True, bucket_bytes=16 << 10)
+        assert (tr.adam_stream is not None) == ov
+        gen = torch.Generator(device=DEV)
+        gen.manual_seed(5)
+        losses = [tr.step(t(spec_in), t(emb), t(spec_out), dropout_mask=eng.make_dropout_mask(gen), return_loss=True) for _ in range(4)]
+        torch.cuda.synchronize()
+        out.append((eng.theta.clone(), eng.adam_m.clone(), eng.adam_v.clone(), {k: v.clone() for k, v in eng.moving.items()}, losses, eng.adam_t))
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert all(torch.equal(a[3][k], b[3][k]) for k in a[3])
+    assert a[4] == b[4] and a[5] == b[5] == 4 and a[4][-1] < a[4][0]
+
+
 @pytest.mark.parametrize("mode,bn", [(0, True), (1, True), (2, True), (3, True), (2, False)])
 def test_feature_block_modes_on_graph_engine(U, mode, bn):
     """dl_models/u_net.py modes 0-3 (convolutional_block_1/2, residual_block_1/2) on UNetGraphEngine vs the oracle."""

@@ -630,13 +630,13 @@ class UNetEngine:
                 ops.conv2d_wgrad(self.geo["head"], self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws_)
         with self._wg() as ws_:
             ops.colsum(gl, g["head.bias"], ws_)
-        ready("head.bias")
         top = self.ab[1] if D >= 1 else self.a[1]
         g_cur = self.g_ab[1] if D >= 1 else self.g_z
         if self.head_direct and self.dtype == "bf16" and ops.head6x6_dgrad_supported(self.W, self.ch[0]):
-            ops.head6x6_dgrad(gl, self.p["head.kernel"], g_cur)
+            ops.head6x6_dgrad(gl, self.p["head.kernel"], g_cur)         # reads the fp32 master kernel: before ready()
         else:
             ops.conv2d_dgrad(self.geo["head"], gl, self.wb("head.kernel"), g_cur)
+        ready("head.bias")      # a group is handed over (all-reduce / optimizer) only after the last reader of its parameters
         for l in range(1, D + 1):
             c = self.ch[l - 1]
             # cb1b
@@ -665,8 +665,8 @@ class UNetEngine:
             if not up_bias_done:
                 with self._wg() as ws_:
                     ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
-            ready(f"dec{l}.up.bias")
             ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, self.wf(f"dec{l}.up.kernel"), g_in)
+            ready(f"dec{l}.up.bias")            # after the last reader of this group's parameters (fp32: wf() is the master kernel)
         # bottleneck: z = a_L + conv1x1(dropout(dense(embedding))).  Nothing downstream of the information-vector branch feeds the
         # encoder's backward chain (that needs only g_z), so the whole branch runs on the weight-gradient stream when there is one.
         B = self.B
