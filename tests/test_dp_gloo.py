@@ -100,6 +100,30 @@ def test_bucket_boundaries_cover_flat_buffer():
     assert all(lo < hi for lo, hi in ranges) and all(ranges[i][1] == ranges[i + 1][0] for i in range(len(ranges) - 1))
 
 
+def test_bucket_hook_sees_every_bucket_once_in_order_without_a_collective():
+    """reduce=False + on_bucket: the schedule the overlapped trainer uses on one replica (Adam per finished bucket).  A bucket
+    is handed over only when mark_ready has covered its end, each exactly once, in flat-buffer order, and finish() flushes
+    the rest; reset() starts a new step."""
+    from unet_rir_amd.trainer import GradBucketer
+    flat = torch.zeros(1000)
+    seen = []
+    b = GradBucketer(flat, [64, 128, 512, 640, 1000], bucket_bytes=1024, reduce=False,
+                     on_bucket=lambda lo, hi, work: seen.append((lo, hi, work)))
+    want = list(b.buckets())
+    for step in range(2):
+        seen.clear()
+        b.reset()
+        b.mark_ready(100)                       # nothing complete yet (first bucket ends at 512)
+        assert seen == []
+        b.mark_ready(600)
+        assert [(lo, hi) for lo, hi, _ in seen] == [w for w in want if w[1] <= 600]
+        b.mark_ready(600)                       # idempotent
+        n_before = len(seen)
+        assert n_before == len([w for w in want if w[1] <= 600])
+        b.finish()
+        assert [(lo, hi) for lo, hi, _ in seen] == want and all(w is None for _, _, w in seen)
+
+
 def test_lr_schedule_matches_reference_formula():
     """main_training.py:342-344: lr * 0.9 ** (epoch / 80) from epoch 80 on (note: not epoch - 80)."""
     from unet_rir_amd.trainer import lr_schedule
