@@ -285,6 +285,25 @@ int unetrir_add_f32_to_bf16(const unetrir_bf16* a, const float* b, unetrir_bf16*
                             unetrir_stream_t stream);
 int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetrir_stream_t stream);
 
+/* ---- waveform <-> feature transforms at the two ends of the data path; all fp32 in HBM,
+ *      fp64 direct DFT inside.  n_fft is a power of two <= 1024, win_length <= n_fft, window = periodic Hann centred in
+ *      n_fft (librosa's default), centred frames (n_fft/2 samples of padding each side), frames = 1 + T / hop_length.
+ *
+ * unetrir_stft_features_f32 replaces Loader.load's mean removal (preprocess.py:56, remove_mean), FeatureExtractor.extract
+ * (preprocess.py:13-18: librosa.stft -> abs, angle), Normalizer.normalize (preprocess.py:26-32, normalize) and
+ * TensorPadder.pad_amp_phase (preprocess.py:65-70): wav [B][T] -> out [B][2][H][W] (plane 0 amplitude, plane 1 phase; row =
+ * frequency bin, column = frame; rows >= n_fft/2+1 and columns >= frames are written as zeros).  pad_mode 0 = 'reflect'
+ * (librosa < 0.10, the reference's era), 1 = 'constant'.  UNETRIR_EINVAL when H < n_fft/2+1, W < frames or T <= n_fft/2.
+ *
+ * unetrir_istft_features_f32 replaces PostProcess.post_process's arithmetic (postprocess.py:68-71, 'ph' branch :127-134):
+ * TensorPadder.un_pad to n_bins x n_frames (preprocess.py:107-113), Normalizer.denormalize (preprocess.py:34-41,
+ * denormalize) and librosa.istft: feat [B][2][H][W] -> wav [B][hop_length * (n_frames - 1)].  n_bins must be n_fft/2+1. */
+int unetrir_stft_frames(int T, int hop_length);
+int unetrir_stft_features_f32(const float* wav, int B, int T, int n_fft, int win_length, int hop_length, int pad_mode,
+                              int remove_mean, int normalize, float* out, int H, int W, unetrir_stream_t stream);
+int unetrir_istft_features_f32(const float* feat, int B, int H, int W, int n_bins, int n_frames, int n_fft, int win_length,
+                               int hop_length, int denormalize, float* wav, unetrir_stream_t stream);
+
 /* ---- profiling hooks used by bench.py: when enabled every conv launch is bracketed by HIP
  *      events on its own stream; collect() synchronises those events and returns, per kernel
  *      family, launch count, total milliseconds and total algorithmic FLOPs. */

@@ -67,6 +67,8 @@ inline ChanPlan chan_plan(long long P, int C, int vec = 4) {
     if (want > maxslab) want = maxslab;
     p.rows_per_slab = (P + want - 1) / want;
     p.nslab = (int)((P + p.rows_per_slab - 1) / p.rows_per_slab);
+    static const int sweep = [] { const char* e = getenv("UNETRIR_CHAN_SWEEP"); return e ? atoi(e) : 1; }();
+    if (sweep) p.rows_per_slab = 0;
     return p;
 }
 
@@ -93,8 +95,11 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
     const int q = blockIdx.y * QB + ql;
     const int c0 = q * V;
     const bool cok = c0 < C;
-    const long long p0 = (long long)blockIdx.x * rows_per_slab;
-    long long p1 = p0 + rows_per_slab;
+    // rows_per_slab > 0: block b owns the contiguous rows [b*rows_per_slab, ...).  rows_per_slab <= 0: the blocks sweep the
+    // tensor together (block b takes row groups b, b+nslab, ...), so the whole grid reads one moving window of HBM instead
+    // of ~2048 separate streams.  Either way a slab is a fixed set of rows summed in a fixed order.
+    long long p0 = (long long)blockIdx.x * rows_per_slab, p1 = p0 + rows_per_slab, pstep = RB;
+    if (rows_per_slab <= 0) { p0 = (long long)blockIdx.x * RB; p1 = P; pstep = (long long)gridDim.x * RB; }
     if (p1 > P) p1 = P;
 
     double s0[V], s1[V];
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
         }
     }
     if (cok) {
-        for (long long p = p0 + rl; p < p1; p += RB) {
+        for (long long p = p0 + rl; p < p1; p += pstep) {
             float xv[V];
             ldv(x + (size_t)p * ldx + c0, xv);
             if (MODE == 0) {

@@ -315,6 +315,42 @@ def head6x6_dgrad(dy: Act, w, dx: Act):
           "head6x6_dgrad")
 
 
+# ---- waveform <-> feature transforms ----------------------------------------------------------------
+
+PAD_MODES = {"reflect": 0, "constant": 1}
+
+
+def stft_frames(T, hop_length):
+    return _lib.lib().unetrir_stft_frames(int(T), int(hop_length))
+
+
+def stft_features(wav, out, n_fft=256, win_length=128, hop_length=64, pad_mode="reflect", remove_mean=True, normalize=True):
+    """wav fp32 [B, T] -> out fp32 [B, 2, H, W] (amplitude / phase planes, zero padded): Loader mean removal +
+    FeatureExtractor.extract + Normalizer.normalize + TensorPadder.pad_amp_phase (preprocess.py:13-18, :26-32, :56, :65-70)."""
+    if wav.dtype != torch.float32 or out.dtype != torch.float32 or not wav.is_contiguous() or not out.is_contiguous():
+        raise ValueError("stft_features takes contiguous fp32 tensors")
+    if wav.dim() != 2 or out.dim() != 4 or out.shape[0] != wav.shape[0] or out.shape[1] != 2:
+        raise ValueError("stft_features: wav [B, T], out [B, 2, H, W]")
+    if pad_mode not in PAD_MODES:
+        raise ValueError(f"pad_mode must be one of {sorted(PAD_MODES)}")
+    B, T = wav.shape
+    check(_lib.lib().unetrir_stft_features_f32(_p(wav), B, T, n_fft, win_length, hop_length, PAD_MODES[pad_mode], int(remove_mean),
+                                               int(normalize), _p(out), out.shape[2], out.shape[3], _stream()), "stft_features")
+
+
+def istft_features(feat, wav, n_bins, n_frames, n_fft=256, win_length=128, hop_length=64, denormalize=True):
+    """feat fp32 [B, 2, H, W] -> wav fp32 [B, hop (n_frames - 1)]: un_pad + Normalizer.denormalize + librosa.istft
+    (postprocess.py:68-71, :127-134; preprocess.py:34-41, :107-113)."""
+    if feat.dtype != torch.float32 or wav.dtype != torch.float32 or not feat.is_contiguous() or not wav.is_contiguous():
+        raise ValueError("istft_features takes contiguous fp32 tensors")
+    if feat.dim() != 4 or feat.shape[1] != 2 or wav.dim() != 2 or wav.shape[0] != feat.shape[0] or \
+            wav.shape[1] != hop_length * (n_frames - 1):
+        raise ValueError("istft_features: feat [B, 2, H, W], wav [B, hop_length * (n_frames - 1)]")
+    B, _, H, W = feat.shape
+    check(_lib.lib().unetrir_istft_features_f32(_p(feat), B, H, W, n_bins, n_frames, n_fft, win_length, hop_length,
+                                                int(denormalize), _p(wav), _stream()), "istft_features")
+
+
 def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_out, ws: Workspace):
     """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits."""
     B, _, H, W = target.shape
