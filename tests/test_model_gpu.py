@@ -406,3 +406,46 @@ def test_device_batch_pipeline(U):
     assert np.isfinite(loss)
     s_in, s_emb, s_out = next(U.synthetic_batches(1, 2, 32, 32, DEV))
     assert float(s_in[:, :, 29:, :].abs().max()) == 0.0 and float(s_in[:, :, :, 31:].abs().max()) == 0.0 and int(s_emb.min()) >= 26
+
+
+def test_inference_on_moving_statistics_and_save_load(U, tmp_path):
+    """`model.model([spec, emb], training=False)` (rir_generation.py:165): BatchNorm normalises with the moving statistics
+    accumulated by the training passes (0.99 / 0.01, Bessel-corrected batch variance), no dropout.  Checked against the
+    oracle after two training forwards; then UNet.save / UNet.load (dl_models/u_net.py:120-163) must reproduce the
+    prediction bit for bit."""
+    H, W, F0, B = 32, 48, 8, 3
+    cfg = R.Config(H, W, F0, 3)
+    Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
+    Pt = {n: torch.tensor(v, dtype=torch.float64) for n, v in Pn.items()}
+    state = {}
+    for n in Pn:
+        if n.endswith(".gamma"):
+            b = n[:-len(".gamma")]
+            state[b + ".moving_mean"] = torch.zeros(Pn[n].shape[0], dtype=torch.float64)
+            state[b + ".moving_variance"] = torch.ones(Pn[n].shape[0], dtype=torch.float64)
+    m = U.UNet((H, W, 2), (2, 16), number_filters_0=F0, kernels=3, batch_size=B, device=DEV, dropout=False)
+    m.engine.load_keras_params(Pn)
+    batches = [R.synthetic_batch(cfg, B, seed_name=f"infer/{i}") for i in range(3)]
+    m.train()
+    with torch.no_grad():
+        for spec_in, emb, _ in batches[:2]:
+            R.forward(Pt, torch.tensor(spec_in, dtype=torch.float64), torch.tensor(emb), cfg, True, None, state)
+            m(torch.tensor(spec_in).to(DEV), torch.tensor(emb).to(DEV))
+    for n, v in state.items():
+        got = m.engine.moving[n].double().cpu()
+        assert float((got - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), n
+    spec_in, emb, _ = batches[2]
+    want = R.forward(Pt, torch.tensor(spec_in, dtype=torch.float64), torch.tensor(emb), cfg, False, None, state)
+    before = {n: v.clone() for n, v in m.engine.moving.items()}
+    x, e = torch.tensor(spec_in).to(DEV), torch.tensor(emb).to(DEV)
+    got = m.predict_stft([x.permute(0, 2, 3, 1), e])                      # NHWC in / out
+    assert got.shape == (B, H, W, 2)
+    assert float((got.permute(0, 3, 1, 2).double().cpu() - want).abs().max()) <= 1e-4
+    for n, v in before.items():                                           # inference leaves the statistics alone
+        assert torch.equal(m.engine.moving[n], v), n
+    m.save(str(tmp_path / "saved"))
+    assert sorted(p.name for p in (tmp_path / "saved").iterdir()) == ["parameters.pkl", "weights.npz"]
+    m2 = U.UNet.load(str(tmp_path / "saved"), batch_size=B, device=DEV)
+    assert (m2.H, m2.W, m2.number_filters_0, m2.kernels, m2.depth) == (H, W, F0, 3, 4)
+    assert torch.equal(m2.engine.theta, m.engine.theta)
+    assert torch.equal(m2.predict_stft([x.permute(0, 2, 3, 1), e]), got)

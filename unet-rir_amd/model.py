@@ -2,6 +2,10 @@
 (dl_models/u_net.py:40-45) and the ``model.model([spec_in, emb], training=...)`` call shape used by
 main_training.py:261 / trainer.py:137, as a ``torch.nn.Module`` whose forward and backward run on the
 HIP engine.  There is no CPU or eager fallback: without the HIP library / a GPU this raises."""
+import os
+import pickle
+
+import numpy as np
 import torch
 from torch import nn
 
@@ -132,6 +136,43 @@ class UNet(nn.Module):
             for n, s_ in eng.specs.items():
                 print(f"  {n:28s} {str(s_.keras_shape):24s}")
             print(f"Total params: {eng.n_params():,}")
+
+    # ---- persistence, dl_models/u_net.py:120-199.  `parameters.pkl` holds the reference's list (u_net.py:180-187) followed by
+    # the arguments it forgets (kernels, depth) - `UNet.load` of the reference feeds BatchNorm into the `kernels` slot because
+    # of that omission; `weights.npz` replaces `weights.h5` (h5py is not part of this image) and holds every variable in its
+    # Keras layout (HWIO Conv2D, HWOI Conv2DTranspose, [in, out] Dense) plus the BatchNorm moving statistics.
+    def save(self, save_folder="."):
+        if self.engine is None:
+            raise RuntimeError("the model has no variables yet: build it with batch_size= or run one forward pass")
+        os.makedirs(save_folder, exist_ok=True)
+        parameters = [self.input_shape, self.inf_vector_shape, self.learning_rate, self.mode, self.number_filters_0,
+                      self.BatchNorm, self.kernels, self.depth]
+        with open(os.path.join(save_folder, "parameters.pkl"), "wb") as f:
+            pickle.dump(parameters, f)
+        arrays = {n: np.asarray(v) for n, v in self.engine.export_keras_params().items()}
+        arrays.update({"moving/" + n: b.detach().cpu().numpy() for n, b in self.engine.moving.items()})
+        np.savez(os.path.join(save_folder, "weights.npz"), **arrays)
+
+    def load_weights(self, weights_path):
+        if self.engine is None:
+            raise RuntimeError("build the model (batch_size=) before loading weights")
+        with np.load(weights_path) as z:
+            self.engine.load_keras_params({n: z[n] for n in self.engine.specs})
+            for n, b in self.engine.moving.items():
+                b.copy_(torch.from_numpy(z["moving/" + n]).to(b.device))
+
+    @classmethod
+    def load(cls, save_folder=".", batch_size=1, device="cuda:0"):
+        with open(os.path.join(save_folder, "parameters.pkl"), "rb") as f:
+            input_shape, inf_vector_shape, lr, mode, f0, bn, kernels, depth = pickle.load(f)
+        ue = cls(input_shape, inf_vector_shape, lr, mode, f0, kernels, bn, depth=depth, batch_size=batch_size, device=device)
+        ue.load_weights(os.path.join(save_folder, "weights.npz"))
+        return ue
+
+    def predict_stft(self, inputs):
+        """dl_models/u_net.py:138-146: model.predict([spectrograms NHWC, vectors]) -> generated spectrograms NHWC."""
+        with torch.no_grad():
+            return self.model(inputs, training=False)
 
     def regularization_losses(self):
         """model.model.losses: one l2(0.001) term per strided Conv2D / Conv2DTranspose kernel."""
