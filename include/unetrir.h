@@ -89,6 +89,13 @@ int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* 
 size_t unetrir_dense_fwd_ws_bytes(int B, int K, int N);
 int unetrir_dense_fwd_f32(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K,
                           int N, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* Data gradient of the same layer from the SAME [N][K] kernel (no transposed copy): dx[b][k] = sum_n dy[b][n] w[n][k] for
+ * B <= 32 batch rows, K % 4 == 0 (unetrir_dense_dgrad_supported).  The kernel streams once with 16-byte loads; n is split
+ * over the workgroups and reduced in a fixed order; ws >= unetrir_dense_dgrad_ws_bytes. */
+int unetrir_dense_dgrad_supported(int B, int K, int N);
+size_t unetrir_dense_dgrad_ws_bytes(int B, int K, int N);
+int unetrir_dense_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx, int B, int K, int N, void* ws,
+                            size_t ws_bytes, unetrir_stream_t stream);
 
 /* [N][T][C] -> [C][T][N] (swap the channel roles of a conv kernel, taps kept). */
 int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C,

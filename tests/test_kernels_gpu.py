@@ -498,6 +498,19 @@ def test_dense_split_k(U, B, K, N):
     ops.dense_fwd(xa, w.to(DEV), b.to(DEV), ya, ws)
     torch.cuda.synchronize()
     close(ya.base.view(B, N), x.double() @ w.double().t() + b.double(), 2e-6 * math.sqrt(K) + 1e-6, "dense fwd")
+    # data gradient from the kernel as stored (no transposed copy): dx = dy . w, rows beyond B untouched, ld > K honoured
+    dy = torch.tensor(detrand.uniform(f"ddy{B,N}", (B, N), -1, 1))
+    assert ops.dense_dgrad_supported(B, K, N) == (B <= 32 and K % 4 == 0)
+    if ops.dense_dgrad_supported(B, K, N):
+        ldx = K + 8
+        dxa = ops.Act(torch.full((B, 1, 1, ldx), 7.0, device=DEV), 0, K)
+        ops.dense_dgrad(ops.Act(dy.view(B, 1, 1, N).to(DEV)), w.to(DEV), dxa, ws)
+        torch.cuda.synchronize()
+        close(dxa.base.view(B, ldx)[:, :K], dy.double() @ w.double(), 2e-6 * math.sqrt(N) + 1e-6, "dense dgrad")
+        assert bool((dxa.base.view(B, ldx)[:, K:] == 7.0).all())
+        again = ops.Act(torch.zeros((B, 1, 1, ldx), device=DEV), 0, K)
+        ops.dense_dgrad(ops.Act(dy.view(B, 1, 1, N).to(DEV)), w.to(DEV), again, ws)
+        assert torch.equal(again.base[..., :K], dxa.base[..., :K])        # fixed-order reduction: bit-reproducible
 
 
 @pytest.mark.parametrize("case", [(2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1), (2, 30, 64, 32, 64, 3, 1), (1, 16, 32, 16, 24, 3, 1)])

@@ -122,6 +122,10 @@ _SIGS = {
                                            c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "unetrir_colsum_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
     "unetrir_cast_weights_batched_bf16": (C.c_int, [C.c_void_p, C.c_int, c_stream]),
+    "unetrir_dense_dgrad_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "unetrir_dense_dgrad_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "unetrir_dense_dgrad_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                          c_stream]),
     "unetrir_stft_frames": (C.c_int, [C.c_int, C.c_int]),
     "unetrir_stft_features_f32": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             c_f32p, C.c_int, C.c_int, c_stream]),

@@ -425,6 +425,17 @@ int unetrir_dense_fwd_f32(const float* x, int ldx, const float* w, const float* 
     return launch_dense_fwd(x, ldx, w, bias, y, ldy, B, K, N, ws, ws_bytes, (hipStream_t)stream);
 }
 
+int unetrir_dense_dgrad_supported(int B, int K, int N) { return dense_dgrad_applies(B, K, N) ? 1 : 0; }
+
+size_t unetrir_dense_dgrad_ws_bytes(int B, int K, int N) { return dense_dgrad_applies(B, K, N) ? dense_dgrad_ws_bytes(B, K, N) : 0; }
+
+int unetrir_dense_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx, int B, int K, int N, void* ws,
+                            size_t ws_bytes, unetrir_stream_t stream) {
+    if (!dy || !w || !dx || !ws || !dense_dgrad_applies(B, K, N) || lddy < N || lddx < K || ((uintptr_t)w & 15) || ((uintptr_t)ws & 15))
+        return UNETRIR_EINVAL;
+    return launch_dense_dgrad(dy, lddy, w, dx, lddx, B, K, N, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C, unetrir_stream_t stream) {
     if (!w || !wt || N <= 0 || T <= 0 || C <= 0) return UNETRIR_EINVAL;
     return launch_transpose_weight(w, wt, N, T, C, (hipStream_t)stream);

@@ -467,6 +467,12 @@ __global__ void splitk_rows_reduce_kernel(const float* __restrict__ part, int ns
     y[p * ldy + n] = s;
 }
 
+int launch_splitk_rows_reduce(const float* part, int nsplit, long long M, int N, const float* bias, float* y, int ldy, hipStream_t s) {
+    const long long tot = M * N;
+    hipLaunchKernelGGL(splitk_rows_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, part, nsplit, M, N, bias, y, ldy);
+    return (int)hipGetLastError();
+}
+
 #define DENSE_KSPLIT 16
 size_t dense_fwd_ws_bytes(int B, int K, int N) { (void)K; return (size_t)DENSE_KSPLIT * B * N * sizeof(float); }
 

@@ -116,4 +116,9 @@ int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int K, int N,
                      void* ws, size_t ws_bytes, hipStream_t s);
 size_t dense_fwd_ws_bytes(int B, int K, int N);
+int launch_splitk_rows_reduce(const float* part, int nsplit, long long M, int N, const float* bias, float* y, int ldy, hipStream_t s);
+bool dense_dgrad_applies(int B, int K, int N);
+size_t dense_dgrad_ws_bytes(int B, int K, int N);
+int launch_dense_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int B, int K, int N, void* ws, size_t ws_bytes,
+                       hipStream_t s);
 int launch_upconv3x3(const Conv3Args& a, int bf16, hipStream_t s);   // H, W = coarse (input) grid; output 2H x 2W

@@ -20,7 +20,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .ops import Act
 
 BN_EPS = 1e-3          # keras BatchNormalization default (dl_models/u_net.py:368)
@@ -230,7 +230,12 @@ class UNetEngine:
         self.g = {n: self.grad[s_.offset:s_.offset + s_.numel].view(s_.shape) for n, s_ in self.specs.items()}
         # transposed work copies: Conv2D kernels for their data gradient, Conv2DTranspose kernels for their forward
         toff, self.tspec = 0, {}
+        # the Dense kernel (49 % of the parameters) needs no transposed copy when its data gradient can read it as stored
+        self.dense_direct = os.environ.get("UNETRIR_DENSE_DGRAD", "1") != "0" and \
+            ops.dense_dgrad_supported(self.B, self.vec_in, self.vec_dim)
         for n, s_ in self.specs.items():
+            if s_.kind == "dense" and self.dense_direct:
+                continue
             if s_.kind in ("conv", "convT", "dense", "conv_padout"):
                 self.tspec[n] = toff
                 toff += -(-s_.numel // ALIGN) * ALIGN
@@ -421,6 +426,8 @@ class UNetEngine:
         for l in range(1, self.L + 1):
             h, w = self.hw[l - 1]
             need = max(need, ops.bn_ws_bytes(self.B * h * w, 2 * self.ch[l - 1]))
+        if self.dense_direct:
+            need = max(need, _lib.lib().unetrir_dense_dgrad_ws_bytes(self.B, self.vec_in, self.vec_dim))
         self.ws.reserve(need)
 
     # ------------------------------------------------------------------ helpers
@@ -687,7 +694,10 @@ class UNetEngine:
                 gv = self.g_vd
             ops.conv2d_wgrad(self.geo["vec.dense"], self.flat, gv, g["vec.dense.kernel"], ws_)
             ops.colsum(gv, g["vec.dense.bias"], ws_)
-            ops.dense_fwd(gv, pt["vec.dense.kernel"], None, self.g_flat, ws_)      # dL/dflat = dv . W (the [in][out] copy)
+            if self.dense_direct:
+                ops.dense_dgrad(gv, p["vec.dense.kernel"], self.g_flat, ws_)           # dL/dflat = dv . W from the kernel as stored
+            else:
+                ops.dense_fwd(gv, pt["vec.dense.kernel"], None, self.g_flat, ws_)      # the same through the [in][out] copy
             ops.embedding_bwd(self.emb_idx, self.g_emb_out, g["vec.embedding"])
         ready("vec.embedding")
         # encoder, deepest level first; the gradient of a_l is (skip half of g_cat_l) + dgrad of the next strided conv

@@ -173,6 +173,18 @@ def dense_fwd(x: Act, w, bias, y: Act, ws: Workspace):
           "dense_fwd")
 
 
+def dense_dgrad_supported(B, K, N):
+    return bool(_lib.lib().unetrir_dense_dgrad_supported(B, K, N))
+
+
+def dense_dgrad(dy: Act, w, dx: Act, ws: Workspace):
+    """dL/dx of Dense(N) (dl_models/u_net.py:259) from the [N][K] kernel as stored: dx[b][k] = sum_n dy[b][n] w[n][k]."""
+    B, N, K = dy.P, dy.C, dx.C
+    ws.reserve(_lib.lib().unetrir_dense_dgrad_ws_bytes(B, K, N))
+    check(_lib.lib().unetrir_dense_dgrad_f32(_p(dy), dy.ld, _p(w), _p(dx), dx.ld, B, K, N, ws.ptr, ws.nbytes, _stream()),
+          "dense_dgrad")
+
+
 def transpose_weight(w, wt, N, T, C_):
     """[N][T][C] -> [C][T][N]."""
     check(_lib.lib().unetrir_transpose_weight_f32(_p(w), _p(wt), N, T, C_, _stream()), "transpose_weight")
