@@ -568,7 +568,7 @@ def test_conv_fused_column_statistics_bf16(U, case):
 def test_cast_weights_batched_bf16(U):
     """The two-launch batched work-copy refresh equals the per-layer calls bit for bit."""
     ops = U.ops
-    shapes = [(16, 9, 8), (72, 9, 40), (128, 1, 64), (8, 36, 64)]
+    shapes = [(16, 9, 8), (72, 9, 40), (128, 1, 64), (8, 36, 64), (128, 9, 64), (64, 9, 192), (192, 3, 128)]   # the last three: fused one-read kernel
     ws, same1, tr1, same2, tr2, ent = [], [], [], [], [], []
     for i, (N, T, Cc) in enumerate(shapes):
         w = torch.tensor(detrand.uniform(f"cwb{i}", (N, T, Cc), -1, 1)).to(DEV)

@@ -7,11 +7,12 @@
 // 268 MB transpose pass per step on top of the 134 MB the product itself has to read.  Here the output columns run along the
 // CONTIGUOUS dimension of w, so the matrix streams once with 16-byte loads and no transpose exists:
 //   * a workgroup is 4 waves; a wave owns 256 output columns (one float4 per lane) and all B <= 32 batch rows: 128 fp32
-//     accumulators per lane, 128 FMAs per 16-byte load (the product is HBM-bound by a factor ~50);
+//     accumulators per lane, 128 FMAs per 16-byte load (16 flop per byte: the balance point of v_pk_fma_f32 against HBM);
 //   * the reduction dimension n is split over blockIdx.y (128 rows per slice): 8 column strips x 32 slices = 256 workgroups
 //     at cfg 2; a slice's dy[b][n] values are staged transposed in LDS and broadcast-read ([n][b]: one ds_read_b128 serves 4
 //     batch rows of every lane);
-//   * 16 rows of w are requested before the first is used (16 KB in flight per wave);
+//   * 16 rows of w are requested before the first is used (16 KB in flight per wave; splitting them into two register
+//     batches so that one is in flight while the other is consumed measured the same 56 us);
 //   * raw partial sums per slice, then the fixed-order splitk_rows_reduce_kernel: deterministic, no atomics.
 // Algorithmic bytes: N*K*4 (w) once; partials add 2 * slices * B * K * 4 (32 MB + 32 MB at cfg 2).
 #include <hip/hip_runtime.h>

@@ -397,9 +397,52 @@ __global__ void transpose_cast_weight_kernel(const float* __restrict__ w, __bf16
 
 // All layers of a model in two launches: desc[l] describes one fp32 master [N][T][C] and its two bf16 work copies
 // (blockIdx.y = layer).  Same element order as cast_weight_kernel / transpose_cast_weight_kernel.
+// layers the fused kernel below takes: both copies wanted, no channel padding, 64 x 64 tiles fit exactly
+__device__ __forceinline__ bool cast_fused_applies(const unetrir_cast_desc& d) {
+    return d.same && d.transposed && d.C == d.Cp && d.N == d.Np && (d.C & 63) == 0 && (d.N & 63) == 0 &&
+           ((((uintptr_t)d.w) & 15) | (((uintptr_t)d.same) & 7) | (((uintptr_t)d.transposed) & 7)) == 0;
+}
+
+// Both work copies from ONE read of the master: a 64 (n) x 64 (c) tile of tap t is loaded with 16-byte accesses, rounded,
+// stored as it lies ([N][T][C]) and, through a padded LDS tile, transposed ([C][T][N]); every global store row is 128 bytes.
+__global__ __launch_bounds__(256) void cast_both_batched_kernel(const unetrir_cast_desc* __restrict__ desc) {
+    __shared__ __bf16 tile[64][66];                       // 132-byte rows: the column gathers below hit 16 banks
+    const unetrir_cast_desc d = desc[blockIdx.y];
+    if (!cast_fused_applies(d)) return;
+    __bf16* __restrict__ same = (__bf16*)d.same;
+    __bf16* __restrict__ wt = (__bf16*)d.transposed;
+    const int ntx = d.C >> 6, nty = d.N >> 6;
+    const int ntiles = ntx * nty * d.T;
+    const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int t = tl / (ntx * nty);
+        const int rem = tl - t * (ntx * nty);
+        const int c0 = (rem % ntx) << 6, n0 = (rem / ntx) << 6;
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * 16 + lr;
+            const size_t off = ((size_t)(n0 + r) * d.T + t) * d.C + c0 + lc;
+            const float4 v = *reinterpret_cast<const float4*>(d.w + off);
+            bf16x4 h;
+            h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+            *reinterpret_cast<bf16x4*>(same + off) = h;
+            tile[r][lc + 0] = h[0]; tile[r][lc + 1] = h[1]; tile[r][lc + 2] = h[2]; tile[r][lc + 3] = h[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int c = ps * 16 + lr;
+            bf16x4 h;
+            h[0] = tile[lc + 0][c]; h[1] = tile[lc + 1][c]; h[2] = tile[lc + 2][c]; h[3] = tile[lc + 3][c];
+            *reinterpret_cast<bf16x4*>(wt + ((size_t)(c0 + c) * d.T + t) * d.N + n0 + lc) = h;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const unetrir_cast_desc* __restrict__ desc) {
     const unetrir_cast_desc d = desc[blockIdx.y];
-    if (!d.same) return;
+    if (!d.same || cast_fused_applies(d)) return;
     __bf16* o = (__bf16*)d.same;
     const size_t total = (size_t)d.N * d.T * d.Cp;
     if (d.C == d.Cp && (total & 7) == 0 && (((uintptr_t)d.w | (uintptr_t)o) & 15) == 0) {     // flat copy, 8 elements per thread
@@ -423,7 +466,7 @@ __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const unetrir
 __global__ __launch_bounds__(256) void transpose_cast_weights_batched_kernel(const unetrir_cast_desc* __restrict__ desc) {
     __shared__ float tile[32][33];
     const unetrir_cast_desc d = desc[blockIdx.y];
-    if (!d.transposed) return;
+    if (!d.transposed || cast_fused_applies(d)) return;
     __bf16* wt = (__bf16*)d.transposed;
     const int ntx = (d.C + 31) / 32, nty = (d.Np + 31) / 32;
     const int ntiles = ntx * nty * d.T;
@@ -532,6 +575,7 @@ int launch_transpose_cast_weight(const float* w, void* wt, int N, int T, int C, 
 }
 
 int launch_cast_weights_batched(const unetrir_cast_desc* desc_dev, int n_layers, hipStream_t s) {
+    hipLaunchKernelGGL(cast_both_batched_kernel, dim3(256, n_layers), dim3(256), 0, s, desc_dev);
     hipLaunchKernelGGL(cast_weights_batched_kernel, dim3(256, n_layers), dim3(256), 0, s, desc_dev);
     hipLaunchKernelGGL(transpose_cast_weights_batched_kernel, dim3(256, n_layers), dim3(256), 0, s, desc_dev);
     return (int)hipGetLastError();
