@@ -39,9 +39,17 @@ __device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * WBUF];
-    const int tid = threadIdx.x, lane = tid & 63;
+// NH = 1: the workgroup above (4 waves, two per CU).  NH = 2: two such wave quartets in ONE workgroup (8 waves, one per CU),
+// each with its own pair of LDS buffers and its own half of the workgroup's split-K slice; they advance in lockstep (the
+// raw barrier is workgroup wide) and at the end the second quartet hands its 144 accumulators per lane to the first through
+// the then idle 160 KB of LDS.  Same occupancy, half as many partial slabs: half the fp32 partial traffic and half the
+// split-K reduction (75 MB written + read per launch with NH = 1).
+template <int NH>
+__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem_all[NH * 2 * WBUF];
+    const int half = NH == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    unsigned char* smem = smem_all + half * 2 * WBUF;
+    const int tid = threadIdx.x & 255, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -51,9 +59,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3Args
     const int n0 = rt * 64, c0 = ct * 64;
     const int per_img = a.npy * a.npx;
     const int G = a.B * per_img;
-    const int g0 = blockIdx.y * a.patches_per_split;
-    int g1 = g0 + a.patches_per_split;
-    if (g1 > G) g1 = G;
+    // the workgroup's slice is NH * patches_per_split patches; quartet `half` takes the half-th part.  Every quartet runs
+    // n_it iterations (the first quartet's count); patches past the end are all-zero DMAs and add nothing.
+    const int G0 = blockIdx.y * NH * a.patches_per_split;
+    const int g0 = G0 + half * a.patches_per_split;
+    const int n_it = min(a.patches_per_split, G - G0);
 
     // ---- DMA lane constants: instruction i covers patch pixels 8i .. 8i+7, lane = (pixel sub, 16-byte granule g8)
     const int g8 = lane & 7, sub = lane >> 3;
@@ -88,6 +98,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3Args
     const int x_rec = (int)((((size_t)a.IH * a.IW - 1) * a.ldx + a.C) * 2), d_rec = (int)((((size_t)a.OH * a.OW - 1) * a.lddy + a.N) * 2);
 
     auto issue = [&](int g, int buf) {
+        const bool gv = g < G;
+        if (!gv) g = G - 1;
         const int img = g / per_img;
         const int rem = g - img * per_img;
         const int pyi = rem / a.npx, pxi = rem - pyi * a.npx;
@@ -104,13 +116,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3Args
             int i = wave + 4 * j;
             if (i > WX_INSTR - 1) i = WX_INSTR - 1;
             const int iy = iy0 + xpr[j], ix = ix0 + xpc[j];
-            const bool ok = xcok[j] && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+            const bool ok = gv && xcok[j] && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
             const uint32_t off = ok ? (uint32_t)(xbase + (int)xrel[j]) : WOOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xb + i * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bool ok = dnok[j] && (py0 + dr_[j]) < a.OH && (px0 + dc_[j]) < a.OW;
+            const bool ok = gv && dnok[j] && (py0 + dr_[j]) < a.OH && (px0 + dc_[j]) < a.OW;
             const uint32_t off = ok ? (uint32_t)(dbase + (int)drel[j]) : WOOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lptr_t)(db + (wave + 4 * j) * 1024), 16, off, 0, 0, 0);
         }
@@ -155,13 +167,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3Args
         MM(6, fd, frag(xl[S2][0], xh[S2][0])); MM(7, fd, frag(xl[S2][1], xh[S2][1])); MM(8, fd, frag(xl[S2][2], xh[S2][2])); \
     } while (0)
 
-    if (g0 < g1) issue(g0, 0);
+    if (n_it > 0) issue(g0, 0);
     int k = 0;
-    for (int g = g0; g < g1; ++g, k ^= 1) {
+    for (int it = 0; it < n_it; ++it, k ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of patch g has landed ...
         __builtin_amdgcn_s_barrier();                            // ... everybody's has; everybody is done reading the other buffer
         asm volatile("" ::: "memory");
-        if (g + 1 < g1) issue(g + 1, k ^ 1);
+        if (it + 1 < n_it) issue(g0 + it + 1, k ^ 1);
         const uint32_t xb = lds0 + k * WBUF, db = xb + WX_BYTES;
         uint32_t xa[4];
 #pragma unroll
@@ -187,6 +199,19 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3Args
 #undef RDD
 #undef RDX
 
+    if constexpr (NH == 2) {
+        // second quartet -> first quartet through LDS: [accumulator register][thread], conflict-free in both directions
+        __syncthreads();                                 // every fragment read of the last patch has been consumed
+        float* red = reinterpret_cast<float*>(smem_all);
+        if (half == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 256 + tid] = acc[t][r];
+        }
+        __syncthreads();
+        if (half == 1) return;
+    }
     float* part = a.part + (size_t)blockIdx.y * a.N * 9 * a.C;
     const int c = c0 + wc * 32 + (lane & 31);
     if (c < a.C) {
@@ -195,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3g_bf16_kernel(const Wgrad3Args
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (n < a.N) part[((size_t)n * 9 + t) * a.C + c] = acc[t][r];
+                float v = acc[t][r];
+                if constexpr (NH == 2) v += reinterpret_cast<const float*>(smem_all)[(t * 16 + r) * 256 + tid];
+                if (n < a.N) part[((size_t)n * 9 + t) * a.C + c] = v;
             }
     }
 }
@@ -223,13 +250,17 @@ int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, v
     if (!on || a.OH % 8 != 0 || x_bytes >= 0x70000000u || d_bytes >= 0x70000000u || (a.C & 7) || (a.N & 7)) return WGRAD3X3R_NOT_TAKEN;
     int ns, per;
     plan_g(a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    static const int nh_env = [] { const char* e = getenv("UNETRIR_WG_NH"); return e ? atoi(e) : 2; }();
+    const int nh = (nh_env == 2 && ns >= 2) ? 2 : 1;
+    ns = (ns + nh - 1) / nh;                             // partial slabs = workgroups along the split dimension
     const size_t nout = (size_t)a.N * 9 * a.C;
     const bool direct = (ns == 1 && reg == 0.f);
     if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return WGRAD3X3R_NOT_TAKEN;
     a.part = direct ? dw : (float*)ws;
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
-    hipLaunchKernelGGL(wgrad3x3g_bf16_kernel, dim3(tiles, ns), dim3(256), 0, s, a);
+    if (nh == 2) hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<2>, dim3(tiles, ns), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<1>, dim3(tiles, ns), dim3(256), 0, s, a);
     const int err = (int)hipGetLastError();
     if (err || direct) return err;
     return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);
