@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
                                                            long long P, int C, int QB, long long rows_per_slab,
                                                            double* __restrict__ part) {
     constexpr int V = VecOf<T>::N;
-    __shared__ double red[256 * 2 * V];
+    __shared__ double red[256 * 4];
     const int tid = threadIdx.x;
     const int RB = 256 / QB;
     const int ql = tid % QB, rl = tid / QB;
@@ -136,17 +136,29 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
             }
         }
     }
+    // cross-row reduction in the block, four values at a time: 8 KB of LDS instead of 32 KB keeps eight blocks on a CU (the
+    // reduction is bandwidth bound: occupancy is what it runs on).  Same fixed summation order as one big exchange.
 #pragma unroll
-    for (int k = 0; k < V; ++k) { red[tid * 2 * V + k] = s0[k]; red[tid * 2 * V + V + k] = s1[k]; }
-    __syncthreads();
-    if (rl == 0 && cok) {
-        for (int r = 1; r < RB; ++r) {
+    for (int ch = 0; ch < 2 * V / 4; ++ch) {
+        if (ch) __syncthreads();
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                s0[k] += red[(r * QB + ql) * 2 * V + k];
-                s1[k] += red[(r * QB + ql) * 2 * V + V + k];
+        for (int j = 0; j < 4; ++j) {
+            const int idx = ch * 4 + j;
+            red[tid * 4 + j] = idx < V ? s0[idx] : s1[idx - V];
+        }
+        __syncthreads();
+        if (rl == 0 && cok) {
+            for (int r = 1; r < RB; ++r) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = ch * 4 + j;
+                    const double v = red[(r * QB + ql) * 4 + j];
+                    if (idx < V) s0[idx] += v; else s1[idx - V] += v;
+                }
             }
         }
+    }
+    if (rl == 0 && cok) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             part[((size_t)blockIdx.x * C + c0 + k) * 2 + 0] = s0[k];
@@ -580,6 +592,10 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096
     if (b < 1) b = 1;
     return (unsigned)b;
 }
+static inline unsigned chan_pad_lds() {      // A/B: UNETRIR_CHAN_OLDLDS=1 pads the block to the 32 KB it used to take (5 blocks per CU)
+    static const unsigned v = [] { const char* e = getenv("UNETRIR_CHAN_OLDLDS"); return (e && e[0] == '1') ? 24576u : 0u; }();
+    return v;
+}
 static inline int bn_nohoist_flag() {
     static const int f = [] { const char* e = getenv("UNETRIR_BN_HOIST"); return (e && e[0] == '0') ? 256 : 0; }();
     return f;
@@ -595,7 +611,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
                   float* moving_mean, float* moving_var, float* affine, float* saved, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
-    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
+    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
     hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
                        beta, eps, momentum, moving_mean, moving_var, affine, saved);
@@ -618,7 +634,7 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
-    hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, da, ldda, affine, saved,
+    hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, da, ldda, affine, saved,
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
@@ -630,7 +646,7 @@ template <typename T>
 int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
-    hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), 0, s, x, ldx, (const T*)nullptr, 0,
+    hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
     hipLaunchKernelGGL(colsum_finalize_kernel<double>, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out, 0);
     return (int)hipGetLastError();
