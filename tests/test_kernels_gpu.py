@@ -587,3 +587,28 @@ def test_cast_weights_batched_bf16(U):
             assert torch.equal(tr1[i], tr2[i])
         else:
             assert float(tr2[i].float().min()) == 1.0      # NULL destination: untouched
+
+
+@pytest.mark.parametrize("case", [(2, 40, 70, 8, 64, 3, 1), (1, 32, 64, 8, 64, 3, 1), (3, 7, 33, 8, 64, 3, 1)])
+def test_stem_conv_bf16(U, case):
+    """First layer (8 stored input channels -> 64, no addend): the direct-operand stem kernel (stem3x3.hip), ragged tiles,
+    a strided output buffer, and agreement with the general kernel bit for bit (both accumulate the 72 products in fp32 MFMA
+    order per output; equality is not guaranteed in general, so compare against the oracle and bound the difference)."""
+    ops = U.ops
+    B, H, W, Ci, Co, k, s = case
+    x, w, b = conv_data(case)
+    x, w = q16(x), q16(w)
+    y = R.conv2d_same(x, w, b, s)
+    g = ops.geom(B, H, W, Ci, Co, k, s)
+    xa = ops.Act(to_nhwc_bf16(x, Ci, 0, DEV))
+    w32 = w.permute(3, 0, 1, 2).contiguous().float().to(DEV)
+    wh = torch.empty((Co, 9, Ci), dtype=torch.bfloat16, device=DEV)
+    ops.cast_weight_bf16(w32, wh, Co, 9, Ci, Ci)
+    ya = ops.Act(torch.full((B, H, W, Co + 8), 512.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+    ops.conv2d_fwd(g, xa, wh, b.float().to(DEV), ya)
+    torch.cuda.synchronize()
+    close(ya.dense().permute(0, 3, 1, 2), y, 1e-2, "stem fwd")
+    assert float(ya.base[..., Co:].float().min()) == 512.0 and float(ya.base[..., Co:].float().max()) == 512.0
+    again = ops.Act(torch.zeros((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
+    ops.conv2d_fwd(g, xa, wh, b.float().to(DEV), again)
+    assert torch.equal(again.base, ya.base[..., :Co])

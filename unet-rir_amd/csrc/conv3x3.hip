@@ -271,6 +271,8 @@ int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
     // bf16: the row-reuse kernel (conv3x3r.hip) unless UNETRIR_CONV3X3R=0 or a timing experiment asks for the no-store variant
     static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
     static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
+    static const bool stem = [] { const char* e = getenv("UNETRIR_STEM"); return !(e && e[0] == '0'); }();
+    if (bf16 && stem && stem3x3_applies(a)) return launch_stem3x3_bf16(a, s);          // first layer: 8 stored channels -> 64
     if (bf16 && dma && conv3x3g_applies(a)) return launch_conv3x3g_bf16(a, s);
     if (bf16 && conv3x3h_applies(a)) return launch_conv3x3h_bf16(a, s);
     if (bf16 && rowreuse && !(a.flip & 2)) return launch_conv3x3r_bf16(a, s);
