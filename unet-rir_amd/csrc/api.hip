@@ -93,14 +93,15 @@ struct BF16 {
 template <class P>
 int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, const typename P::T* w, const float* bias,
                   const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s, float* colstat = nullptr) {
-    if (use_conv3x3(g->k, g->stride, g->H, g->W)) {
+    if (g->k == 3 && g->stride == 1) {
         Conv3Args c{};
         c.colstat = colstat;
         c.in = x; c.ldi = ldx; c.w = w; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = y; c.ldo = ldy;
         c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout;
         static const int nostore = [] { const char* e = getenv("UNETRIR_CONV3X3_NOSTORE"); return (e && e[0] == '1') ? 2 : 0; }();
         c.flip = nostore;
-        return launch_conv3x3(c, P::is_bf16, s);
+        // narrow images (the 16 x 16 level) would half-fill the 32-column tiles: bf16 has a paired-image tile for them
+        if (use_conv3x3(g->k, g->stride, g->H, g->W) || (P::is_bf16 && conv3x3g_pair_applies(c))) return launch_conv3x3(c, P::is_bf16, s);
     }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
@@ -121,12 +122,12 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
 template <class P>
 int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int lddy, const typename P::T* wt, const float* bias,
                     const typename P::T* addend, int ldadd, typename P::T* dx, int lddx, hipStream_t s, float* colstat = nullptr) {
-    if (use_conv3x3(g->k, g->stride, g->H, g->W)) {     // dgrad of a stride-1 3x3 conv = the same conv with flipped taps
+    if (g->k == 3 && g->stride == 1) {     // dgrad of a stride-1 3x3 conv = the same conv with flipped taps
         Conv3Args c{};
         c.colstat = colstat;
         c.in = dy; c.ldi = lddy; c.w = wt; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = dx; c.ldo = lddx;
         c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cout; c.N = g->Cin; c.flip = 1;
-        return launch_conv3x3(c, P::is_bf16, s);
+        if (use_conv3x3(g->k, g->stride, g->H, g->W) || (P::is_bf16 && conv3x3g_pair_applies(c))) return launch_conv3x3(c, P::is_bf16, s);
     }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
@@ -327,11 +328,12 @@ int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy
 /* Fused column statistics: the 3x3 stride-1 kernels conv3x3g / conv3x3r<4,1> can emit, per 16 x 32 pixel tile, the
  * per-channel (sum, sum of squares) of the bf16 output they store.  rows == 0: the kernel serving this layer cannot. */
 static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) {
-    if (!geom_ok(g) || !use_conv3x3(g->k, g->stride, g->H, g->W)) return 0;
+    if (!geom_ok(g) || g->k != 3 || g->stride != 1) return 0;
     Conv3Args c{};
     c.B = g->B; c.H = g->H; c.W = g->W; c.ldi = ld_in;
     c.C = dgrad ? g->Cout : g->Cin; c.N = dgrad ? g->Cin : g->Cout; c.flip = dgrad ? 1 : 0;
-    if (!conv3x3_has_colstat(c)) return 0;
+    if (conv3x3g_pair_applies(c)) return conv3x3g_colstat_rows(c);          // two images per tile row
+    if (!use_conv3x3(g->k, g->stride, g->H, g->W) || !conv3x3_has_colstat(c)) return 0;
     return (long long)g->B * ((g->H + 15) / 16) * ((g->W + 31) / 32);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }

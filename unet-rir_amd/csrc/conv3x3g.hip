@@ -57,9 +57,22 @@ constexpr int GSROW = 64 * 2 + 16;
 constexpr int GSMEM = 2 * GP_BYTES + 3 * GW_BYTES;   // 153600
 }  // namespace
 
-template <int VAR>
+// PAIR (images at most 16 pixels wide, the 16 x 16 level): a tile is 16 rows x 16 columns of TWO consecutive images.  Their
+// 18 x 18 patches are stacked in LDS (36 rows of 18 pixels), so the second 16-pixel half of a fragment row is the other
+// image, one constant offset away, and nothing else in the pipeline changes - full tiles where the 32-column tile would be
+// half empty.
+template <int VAR, bool PAIR = false>
 __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GSMEM];
+    constexpr int PC = PAIR ? 18 : GPC;                    // patch columns
+    constexpr int NPX = PAIR ? 36 * 18 : GNPX;             // patch pixels
+    constexpr int P_INSTR = (NPX + 15) / 16;               // 41 / 39 wave-instructions
+    constexpr int P_BYTES = P_INSTR * 1024;
+    constexpr int P_PER_WAVE = (P_INSTR + 7) / 8;
+    constexpr int RP = PC * 64;                            // patch row pitch, bytes
+    constexpr int HO = PAIR ? 18 * RP : 1024;              // second half of a fragment row: the other image / 16 columns on
+    constexpr int SMEM = 2 * P_BYTES + 3 * GW_BYTES;       // 157696 / 153600
+    static_assert(!PAIR || (VAR & 2), "the paired tile exists for the 16x16x32 body only");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const __bf16* __restrict__ w = (const __bf16*)a.w;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -69,14 +82,16 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr bool S16 = (VAR & 2) != 0;              // v_mfma_f32_16x16x32_bf16 body
 
-    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + GTR - 1) / GTR;
+    const int tiles_x = PAIR ? 1 : (a.W + 31) / 32, tiles_y = (a.H + GTR - 1) / GTR;
     const int ntN = (a.N + GBN - 1) / GBN;
     int id = blockIdx.x;
     if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);   // neighbouring tiles on one XCD (shared L2)
     const int nt = id % ntN; id /= ntN;
     const int tx = id % tiles_x; id /= tiles_x;
     const int ty = id % tiles_y;
-    const int img = id / tiles_y;
+    const int img = id / tiles_y;                          // PAIR: index of the image pair
+    const int img0 = PAIR ? 2 * img : img;
+    const int nimg = PAIR ? (a.B - img0 < 2 ? a.B - img0 : 2) : 1;
     const int y0 = ty * GTR, x0 = tx * 32, n0 = nt * GBN;
     const int C = a.C;
     const int nch = C / 32;
@@ -86,22 +101,24 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     // invalid lanes (halo outside the image, channels >= N) carry an offset past num_records and read zeros
     constexpr uint32_t OOB = 0xF0000000u;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(in + (size_t)img * a.H * a.W * a.ldi), (short)0, (int)((((size_t)a.H * a.W - 1) * a.ldi + C) * 2), 0x00020000);
+        (void*)(in + (size_t)img0 * a.H * a.W * a.ldi), (short)0, (int)((((size_t)nimg * a.H * a.W - 1) * a.ldi + C) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w, (short)0, (int)((size_t)a.N * ldw * 2), 0x00020000);
     const int slot = lane & 3, sub = lane >> 2;
-    uint32_t pa[GP_PER_WAVE];
-    int pi[GP_PER_WAVE];
+    uint32_t pa[6];                                   // (fixed bounds: arrays of a template-dependent size captured by the
+    int pi[6];                                        //  lambdas below lose the kernel's host stub with this compiler)
+    static_assert(P_PER_WAVE <= 6, "patch instructions per wave");
 #pragma unroll
-    for (int j = 0; j < GP_PER_WAVE; ++j) {
+    for (int j = 0; j < P_PER_WAVE; ++j) {
         int i = wave + 8 * j;
-        if (i > GP_INSTR - 1) i = GP_INSTR - 1;          // wave 7's fifth instruction repeats the last one (uniform DMA counts)
+        if (i > P_INSTR - 1) i = P_INSTR - 1;            // the last waves repeat the final instruction (uniform DMA counts)
         pi[j] = i;
         const int p = 16 * i + sub;
-        const int pr = p / GPC, pc = p - pr * GPC;
+        const int pr = p / PC, pc = p - pr * PC;
+        const int im = PAIR ? pr / 18 : 0;               // PAIR: patch rows 18..35 belong to the second image
         const int gs = S16 ? slot ^ ((pc & 4) >> 1) : slot ^ ((pc >> 2) & 3);
-        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
-        const bool ok = p < GNPX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        pa[j] = ok ? (uint32_t)(((iy * a.W + ix) * a.ldi + gs * 8) * 2) : OOB;
+        const int iy = y0 - 1 + pr - 18 * im, ix = x0 - 1 + pc;
+        const bool ok = p < NPX && im < nimg && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        pa[j] = ok ? (uint32_t)((((im * a.H + iy) * a.W + ix) * a.ldi + gs * 8) * 2) : OOB;
     }
     uint32_t wp[GW_PER_WAVE];
     const int dxs = ((a.flip & 1) ? -C : C) * 2;        // weight-tap step per dx, bytes
@@ -115,14 +132,14 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
         wp[j] = n < a.N ? (uint32_t)((n * ldw + tap0 * C + gs * 8) * 2) : OOB;
     }
     auto issue_p = [&](int ch) {
-        unsigned char* dst = smem + (ch & 1) * GP_BYTES;
+        unsigned char* dst = smem + (ch & 1) * P_BYTES;
         const uint32_t c0b = ch * 64;
 #pragma unroll
-        for (int j = 0; j < GP_PER_WAVE; ++j)
+        for (int j = 0; j < P_PER_WAVE; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(dst + pi[j] * 1024), 16, pa[j] + c0b, 0, 0, 0);
     };
     auto issue_w = [&](int ch, int dx, int buf) {
-        unsigned char* dst = smem + 2 * GP_BYTES + buf * GW_BYTES;
+        unsigned char* dst = smem + 2 * P_BYTES + buf * GW_BYTES;
         const uint32_t off = ch * 64 + dx * dxs;
 #pragma unroll
         for (int j = 0; j < GW_PER_WAVE; ++j)
@@ -158,13 +175,13 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     // fragment addresses: weights  row (dy*128 + wn*64 + j*32 + l31) * 64 + ((kk*2+hi)*16 ^ swz(l31))
     //                     patch    ((4*wm + r) * 34 + l31 + dx) * 64 + ((kk*2+hi)*16 ^ swz(l31 + dx))
-    const uint32_t b_lane = lds0 + 2 * GP_BYTES + (wn * 64 + l31) * 64;
+    const uint32_t b_lane = lds0 + 2 * P_BYTES + (wn * 64 + l31) * 64;
     const uint32_t b_swz = (l31 & 12) << 2;
-    const uint32_t a_lane = lds0 + (4 * wm * GPC + l31) * 64;
+    const uint32_t a_lane = lds0 + (4 * wm * PC + l31) * 64;
 
     for (int ch = 0; ch < nch; ++ch) {
         const bool more = ch + 1 < nch;
-        const uint32_t a_chunk = a_lane + (ch & 1) * GP_BYTES;
+        const uint32_t a_chunk = a_lane + (ch & 1) * P_BYTES;
 #pragma unroll 1
         for (int dx = 0; dx < 3; ++dx) {
             // ---- prefetch: weight tile of step s+2 (ring slot (dx+2)%3), patch of the next chunk
@@ -179,15 +196,15 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             const uint32_t a_dx = a_chunk + dx * 64;
             const uint32_t a_swz = ((l31 + dx) & 12) << 2;
             const uint32_t b_buf = b_lane + dx * GW_BYTES;
-            const uint32_t b_buf16 = lds0 + 2 * GP_BYTES + dx * GW_BYTES + (wn * 64 + l15) * 64;
+            const uint32_t b_buf16 = lds0 + 2 * P_BYTES + dx * GW_BYTES + (wn * 64 + l15) * 64;
             if constexpr (S16) {
                 // one pass over the 32-channel chunk: lane (l15, lq) reads granule lq of row l15 (weights: channel, patch: pixel)
                 const uint32_t ba = b_buf16 + ((lq << 4) ^ ((l15 & 4) << 3));
-                const uint32_t aa = lds0 + (ch & 1) * GP_BYTES + (4 * wm * GPC + l15 + dx) * 64 + ((lq << 4) ^ (((l15 + dx) & 4) << 3));
+                const uint32_t aa = lds0 + (ch & 1) * P_BYTES + (4 * wm * PC + l15 + dx) * 64 + ((lq << 4) ^ (((l15 + dx) & 4) << 3));
                 u32x4 wf[3][4], pf[6][2];
 #define RDW(dy) DSR128(wf[dy][0], ba, dy * 8192 + 0); DSR128(wf[dy][1], ba, dy * 8192 + 1024); \
                 DSR128(wf[dy][2], ba, dy * 8192 + 2048); DSR128(wf[dy][3], ba, dy * 8192 + 3072)
-#define RDP(r) DSR128(pf[r][0], aa, r * 2176 + 0); DSR128(pf[r][1], aa, r * 2176 + 1024)
+#define RDP(r) DSR128(pf[r][0], aa, r * RP + 0); DSR128(pf[r][1], aa, r * RP + HO)
 #define ROWS16(r)                                                                              \
     _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) {                                         \
         if (r - dy < 0 || r - dy > 3) continue;                                                \
@@ -219,16 +236,16 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
                 u32x4 w00, w01, w10, w11, w20, w21, p0, p1, p2, p3, p4, p5;
                 DSR128(w00, ba, 0 * 8192 + 0);
                 DSR128(w01, ba, 0 * 8192 + 2048);
-                DSR128(p0, aa, 0 * 2176);
+                DSR128(p0, aa, 0 * RP);
                 DSR128(w10, ba, 1 * 8192 + 0);
                 DSR128(w11, ba, 1 * 8192 + 2048);
-                DSR128(p1, aa, 1 * 2176);
+                DSR128(p1, aa, 1 * RP);
                 DSR128(w20, ba, 2 * 8192 + 0);
                 DSR128(w21, ba, 2 * 8192 + 2048);
-                DSR128(p2, aa, 2 * 2176);
-                DSR128(p3, aa, 3 * 2176);
-                DSR128(p4, aa, 4 * 2176);
-                DSR128(p5, aa, 5 * 2176);
+                DSR128(p2, aa, 2 * RP);
+                DSR128(p3, aa, 3 * RP);
+                DSR128(p4, aa, 4 * RP);
+                DSR128(p5, aa, 5 * RP);
                 // counted waits: the reads return in issue order, each MFMA group starts as soon as its fragments are in
                 __builtin_amdgcn_s_setprio(1);
                 if constexpr (VAR & 1) LGKM_WAIT(9); else if constexpr (9 == 9) LGKM_WAIT(0);
@@ -256,10 +273,10 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             // ---- retire what the next step reads; younger DMAs stay in flight across the barrier
             if constexpr (!(VAR & 8)) {
             if (dx == 0) {
-                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // W(s+2) + P(ch+1) may remain
+                if (more) { if constexpr (P_PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }   // W(s+2) + P(ch+1) may remain
                 else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");        // W(s+2) may remain
             } else if (dx == 1) {
-                if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // P(ch+1) + W(s+2) may remain
+                if (more) { if constexpr (P_PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }   // P(ch+1) + W(s+2) may remain
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // W(s+2) may remain; P(ch+1) is older: retired
@@ -329,10 +346,11 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int p = ps * 8 + pl;
-            const int y = y0 + 4 * wm + 2 * half + (p >> 5), x = x0 + (p & 31);
-            if (y >= a.H || x >= a.W || nq >= a.N) continue;
+            const int y = y0 + 4 * wm + 2 * half + (p >> 5), x = PAIR ? (p & 15) : x0 + (p & 31);
+            const int imo = PAIR ? img0 + ((p >> 4) & 1) : img;          // PAIR: the second 16-pixel half is the second image
+            if (y >= a.H || x >= a.W || nq >= a.N || imo >= a.B) continue;
             uint4 v = *reinterpret_cast<const uint4*>(stage + p * GSROW + cq * 16);
-            const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+            const size_t pix = ((size_t)imo * a.H + y) * a.W + x;
             if (addend) {
                 const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addend + pix * a.ldadd + nq);
                 bf16x8 vv = __builtin_bit_cast(bf16x8, v);
@@ -380,7 +398,30 @@ bool conv3x3g_applies(const Conv3Args& a) {
     return a.C % 32 == 0 && a.N > 64 && !(a.flip & 2) && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
 }
 
+// images at most 16 pixels wide: the paired-image tile (full tiles where the 32-column tile would be half empty)
+bool conv3x3g_pair_applies(const Conv3Args& a) {
+    // UNETRIR_CONV3X3G_PAIR: 0 = off, 2 = whenever the shape allows (tests), default = only when the paired tiles still give at
+    // least 128 workgroups (1024 -> 1024 at 16 x 16, batch 32: 190 us against 219 us for the tap-table kernel; 512 -> 512 has
+    // 64 workgroups and loses 95 : 85).  Read on every call so that a test can switch it.
+    const char* e = getenv("UNETRIR_CONV3X3G_PAIR");
+    const int mode = e ? atoi(e) : 1;
+    const size_t pair_bytes = (((size_t)2 * a.H * a.W - 1) * a.ldi + a.C) * 2;
+    if (mode == 0 || !conv3x3g_applies(a) || a.W > 16 || a.B < 2 || pair_bytes >= 0x70000000u) return false;
+    const long long wgs = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR) * ((a.N + GBN - 1) / GBN);
+    return mode == 2 || wgs >= 128;
+}
+
+long long conv3x3g_colstat_rows(const Conv3Args& a) {
+    const long long ty = (a.H + GTR - 1) / GTR;
+    return conv3x3g_pair_applies(a) ? (long long)((a.B + 1) / 2) * ty : (long long)a.B * ty * ((a.W + 31) / 32);
+}
+
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
+    if (conv3x3g_pair_applies(a)) {
+        const long long tiles = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR) * ((a.N + GBN - 1) / GBN);
+        hipLaunchKernelGGL((conv3x3g_bf16_kernel<2, true>), dim3((unsigned)tiles), dim3(512), 0, s, a);
+        return (int)hipGetLastError();
+    }
     const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);
     static const int var = [] { const char* e = getenv("UNETRIR_G_VAR"); return e ? atoi(e) : 2; }();
     // UNETRIR_G_VAR=30: timing ablation (no DMA, no vmcnt wait, no barrier in the K loop; results invalid): measured 102 us vs

@@ -109,6 +109,8 @@ int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const 
 bool upconv3x3g_applies(const Conv3Args& a);
 int launch_upconv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3g_applies(const Conv3Args& a);
+bool conv3x3g_pair_applies(const Conv3Args& a);     // images <= 16 pixels wide: two images per tile
+long long conv3x3g_colstat_rows(const Conv3Args& a);
 bool stem3x3_applies(const Conv3Args& a);
 int launch_stem3x3_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3_has_colstat(const Conv3Args& a);
