@@ -95,7 +95,7 @@ def run_mode(U, args, dtype, world, rank, device, steps, warmup):
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[device.index])
             torch.cuda.synchronize()
 
     for _ in range(warmup):
@@ -183,7 +183,15 @@ def main():
     if world > 1 or os.environ.get("UNETRIR_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # No device_id: RCCL's communicator and its internal stream are then created at the first collective, AFTER the engine
+        # has probed and chosen its own concurrent streams.  HIP multiplexes streams onto a few hardware queues; created first,
+        # RCCL's stream can share a queue with the main or the weight-gradient stream, and its event waits (a gradient bucket
+        # waiting for the backward pass) then stall every kernel queued behind them: measured 15.0-15.3 instead of 13.9 ms per
+        # step in about half of the runs (1-rank rehearsal, UNETRIR_FORCE_DP=1); created afterwards it lands on a free queue.
+        if os.environ.get("UNETRIR_BENCH_EAGER_PG") == "1":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import unet_rir_amd as U
     H = W = args.size

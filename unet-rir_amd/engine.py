@@ -102,6 +102,7 @@ class _SideStream:
         eng.wg_stream.wait_event(ev)
         self.ctx = torch.cuda.stream(eng.wg_stream)
         self.ctx.__enter__()
+        eng._flush_ready()         # buckets whose hand-over was deferred to this event (see UNetEngine.backward.ready)
         return eng.ws_w
 
     def __exit__(self, *exc):
@@ -156,6 +157,8 @@ class UNetEngine:
         self._reserve_workspace()
         self.training = True
         self.t_dirty = True
+        self._pending_ready = []
+        self._defer_ready = os.environ.get("UNETRIR_DEFER_READY", "1") != "0"      # A/B switch
         # overlap_wgrad: weight gradients depend only on tensors the main stream has already produced, so they can run on a
         # side HIP stream (own scratch buffer) beside the dgrad -> BatchNorm-backward chain.  Measured -0.5 ms per step
         # (3 %) in bf16 at cfg 2 (scripts/overlap_ab.py, alternating engines in one process), 0 % in fp32.  bench.py turns
@@ -620,8 +623,13 @@ class UNetEngine:
                 on_ready(off)
                 return
             # A bucket's gradients come from both streams (weight gradients: side stream; BatchNorm / fused bias
-            # gradients: main stream).  Let the SIDE stream wait for the main stream's progress and hand the bucket over
-            # from there: the all-reduce orders after both, and the main stream never blocks on the side stream.
+            # gradients: main stream).  The SIDE stream hands the bucket over once it has waited for the main stream's
+            # progress: the all-reduce orders after both and the main stream never blocks on the side stream.  That wait is
+            # the one the next `with self._wg()` performs anyway, so the hand-over is parked until then instead of putting an
+            # event record of its own into the main stream (each costs ~8 us of dispatch gap; later is always safe).
+            if self._defer_ready:
+                self._pending_ready.append((on_ready, off))
+                return
             ev = torch.cuda.Event()
             ev.record()
             self.wg_stream.wait_event(ev)
@@ -722,10 +730,19 @@ class UNetEngine:
                 skip = self.g_cat[l - 1].slice(0, self.ch[l - 2])
                 ops.conv2d_dgrad(self.geo[f"enc{l}.down"], self.g_down[l], self.wb(f"enc{l}.down.kernel"), skip, addend=skip)
                 g_a = skip
+        if self._pending_ready:
+            with self._wg():
+                pass            # hands over what is still parked
         self._join_wg()     # the optimizer (and the next forward, which overwrites activations) must see every weight gradient
 
     def _wg(self):
         return _SideStream(self)
+
+    def _flush_ready(self):
+        """Called on the side stream right after it has waited for the main stream: hand over the parked buckets."""
+        pend, self._pending_ready = self._pending_ready, []
+        for fn, off in pend:
+            fn(off)
 
     def _join_wg(self):
         if self.wg_stream is not None:
