@@ -35,7 +35,8 @@ def screen(name, launch, out):
 
 
 total = 0
-for (B, HW, Ci, Co) in [(8, 128, 128, 128), (8, 64, 256, 256), (4, 256, 64, 64), (4, 256, 128, 64), (16, 32, 512, 512)]:
+for (B, HW, Ci, Co) in [(8, 128, 128, 128), (8, 64, 256, 256), (4, 256, 64, 64), (4, 256, 128, 64), (16, 32, 512, 512),
+                       (32, 16, 1024, 1024)]:      # the last: paired-image tile of conv3x3g, two-quartet wgrad3x3g
     g = ops.geom(B, HW, HW, Ci, Co, 3, 1)
     x, y = ops.Act(rnd((B, HW, HW, Ci))), ops.Act(rnd((B, HW, HW, Co)))
     wh, wt = rnd((Co, 9, Ci), 0.1), rnd((Ci, 9, Co), 0.1)
