@@ -596,7 +596,7 @@ def test_cast_weights_batched_bf16(U):
             assert float(tr2[i].float().min()) == 1.0      # NULL destination: untouched
 
 
-@pytest.mark.parametrize("case", [(2, 40, 70, 8, 64, 3, 1), (1, 32, 64, 8, 64, 3, 1), (3, 7, 33, 8, 64, 3, 1)])
+@pytest.mark.parametrize("case", [(2, 40, 70, 8, 64, 3, 1), (1, 32, 64, 8, 64, 3, 1), (3, 7, 33, 8, 64, 3, 1), (2, 20, 40, 8, 128, 3, 1)])
 def test_stem_conv_bf16(U, case):
     """First layer (8 stored input channels -> 64, no addend): the direct-operand stem kernel (stem3x3.hip), ragged tiles,
     a strided output buffer, and agreement with the general kernel bit for bit (both accumulate the 72 products in fp32 MFMA

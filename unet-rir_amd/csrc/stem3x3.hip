@@ -1,5 +1,5 @@
 // stem3x3.hip - bf16 3x3 stride-1 'same' convolution for the network's first layer (gfx950): 8 stored input channels
-// (2 real + 6 zero, one 16-byte pixel), 64 output channels (encoding_block level 0, dl_models/u_net.py:269-276 with
+// (2 real + 6 zero, one 16-byte pixel), output channels in blocks of 64 (encoding_block level 0, dl_models/u_net.py:269-276 with
 // resize_factor_0 = [1, 1]).
 //
 // The layer is 19 GFLOP against a 268 MB bf16 output at cfg 2: HBM-write bound by a factor ~8, so the kernel is built
@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void stem3x3_bf16_kernel(const Conv3Args a) {
     unsigned char* stage = stage_all + wave * 32 * STEM_SROW;
 
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 4 * STEM_ROWS - 1) / (4 * STEM_ROWS);
+    const int ntN = a.N >> 6;                                // 64 output channels per workgroup (N % 64 == 0)
     int id = blockIdx.x;
+    const int n0 = (id % ntN) << 6; id /= ntN;
     const int tx = id % tiles_x; id /= tiles_x;
     const int ty = id % tiles_y;
     const int img = id / tiles_y;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void stem3x3_bf16_kernel(const Conv3Args a) {
     for (int s = 0; s < 5; ++s)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int t = 2 * s + hi, n = 32 * j + l31;
+            const int t = 2 * s + hi, n = n0 + 32 * j + l31;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (t < 9 && n < a.N) v = *reinterpret_cast<const uint4*>(w + ((size_t)n * 9 + t) * 8);
             wf[s][j] = __builtin_bit_cast(bf16x8, v);
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void stem3x3_bf16_kernel(const Conv3Args a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            const int n = 32 * j + 8 * qd + 4 * hi;
+            const int n = n0 + 32 * j + 8 * qd + 4 * hi;
             bv[j][qd] = (a.bias && n + 3 < a.N) ? *reinterpret_cast<const float4*>(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     // per-lane tap geometry: half-step s -> tap t = 2s + hi -> (dy, dx)
@@ -110,19 +112,19 @@ __global__ __launch_bounds__(256) void stem3x3_bf16_kernel(const Conv3Args a) {
             const int p = ps * 8 + pl, x = x0 + p;
             if (x >= a.W) continue;
             const uint4 v = *reinterpret_cast<const uint4*>(stage + p * STEM_SROW + cq * 16);
-            *reinterpret_cast<uint4*>(out + (((size_t)img * a.H + y) * a.W + x) * a.ldo + cq * 8) = v;
+            *reinterpret_cast<uint4*>(out + (((size_t)img * a.H + y) * a.W + x) * a.ldo + n0 + cq * 8) = v;
         }
     }
 }
 
-// bf16, exactly 8 stored input channels and 64 output channels, plain forward (no addend, no fused statistics)
+// bf16, exactly 8 stored input channels, output channels in blocks of 64, plain forward (no addend, no fused statistics)
 bool stem3x3_applies(const Conv3Args& a) {
-    return a.C == 8 && a.N == 64 && a.flip == 0 && !a.addend && !a.colstat && a.ldi >= 8 && (a.ldi & 7) == 0 && (a.ldo & 7) == 0 &&
+    return a.C == 8 && a.N >= 64 && (a.N & 63) == 0 && a.flip == 0 && !a.addend && !a.colstat && a.ldi >= 8 && (a.ldi & 7) == 0 && (a.ldo & 7) == 0 &&
            (((uintptr_t)a.in | (uintptr_t)a.w | (uintptr_t)a.out) & 15) == 0 && (!a.bias || ((uintptr_t)a.bias & 15) == 0);
 }
 
 int launch_stem3x3_bf16(const Conv3Args& a, hipStream_t s) {
-    const long long tiles = (long long)a.B * ((a.H + 4 * STEM_ROWS - 1) / (4 * STEM_ROWS)) * ((a.W + 31) / 32);
+    const long long tiles = (long long)a.B * ((a.H + 4 * STEM_ROWS - 1) / (4 * STEM_ROWS)) * ((a.W + 31) / 32) * (a.N >> 6);
     hipLaunchKernelGGL(stem3x3_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
