@@ -32,5 +32,6 @@ for HW, C in ((256, 64), (128, 128), (64, 256), (32, 512)):
     t_s = timeit(lambda: ops.bn_stats(x, gamma, beta, affine, saved, ws))
     t_b = timeit(lambda: ops.bn_bwd(da, x, gamma, affine, saved, dx, dg, db, ws))
     t_c = timeit(lambda: ops.colsum(x, db, ws))
+    t_a = timeit(lambda: ops.bn_apply(x, affine, dx, relu=True))
     print(f"sweep={os.environ.get('UNETRIR_CHAN_SWEEP','1')} {HW}x{HW}x{C}: bn_stats {t_s:.1f} us ({nbytes/t_s/1e6:.2f} TB/s)  "
-          f"bn_bwd {t_b:.1f} us ({5*nbytes/t_b/1e6:.2f} TB/s over 5 passes)  colsum {t_c:.1f} us ({nbytes/t_c/1e6:.2f} TB/s)")
+          f"bn_bwd {t_b:.1f} us ({5*nbytes/t_b/1e6:.2f} TB/s over 5 passes)  colsum {t_c:.1f} us ({nbytes/t_c/1e6:.2f} TB/s)  bn_apply {t_a:.1f} us ({2*nbytes/t_a/1e6:.2f} TB/s) nt={os.environ.get('UNETRIR_BN_NT','0')}")
