@@ -154,6 +154,31 @@ def test_two_kernels_one_operator_at_full_size(U):
     assert float((a != b).float().mean()) < 0.2                  # most elements round identically
 
 
+def test_paired_tile_matches_tap_table_kernel_at_full_size(U, monkeypatch):
+    """The 16 x 16 level (1024 -> 1024 channels, batch 32): conv3x3g's paired-image tile against the tap-table kernel the layer
+    used before, forward and data gradient; different K order, so agreement to the bf16 rounding of the stored result."""
+    ops = U.ops
+    C, HW = 1024, 16
+    x = ops.Act(_rand_bf16((B, HW, HW, C), 41))
+    w32, wh, wt = _weights(ops, C, C, 42)
+    g = ops.geom(B, HW, HW, C, C, 3, 1)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UNETRIR_CONV3X3G_PAIR", mode)
+        y = ops.Act(torch.empty((B, HW, HW, C), dtype=torch.bfloat16, device=DEV))
+        dx = ops.Act(torch.empty((B, HW, HW, C), dtype=torch.bfloat16, device=DEV))
+        ops.conv2d_fwd(g, x, wh, None, y)
+        ops.conv2d_dgrad(g, x, wt, dx)
+        torch.cuda.synchronize()
+        res[mode] = (y.base.float(), dx.base.float())
+    assert ops.conv2d_colstat_rows(g, 0, x) == 0                   # (mode 0 is in force here: no fused statistics on that path)
+    monkeypatch.setenv("UNETRIR_CONV3X3G_PAIR", "1")
+    assert ops.conv2d_colstat_rows(g, 0, x) == B // 2              # one statistics row per image pair
+    for a, b in zip(res["1"], res["0"]):
+        assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())
+        assert float((a != b).float().mean()) < 0.2
+
+
 def test_train_step_invariants_at_full_size(U):
     H = W = 256
     eng = U.UNetEngine(H, W, B, F0=64, dtype="bf16", device=DEV)
