@@ -103,7 +103,9 @@ def run_mode(U, args, dtype, world, rank, device, steps, warmup):
     sync()
     prof = (not args.no_prof) and rank == 0
     if prof:
-        U.ops.prof_enable(True)
+        # overlapped schedule: only the forward brackets are clean kernel durations (see below), so only those are taken -
+        # every bracket is two event records in the stream (~8 us of dispatch gap each)
+        U.ops.prof_enable(2 if overlap and os.environ.get("UNETRIR_BENCH_PROF_ALL") != "1" else 1)
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step(spec_in, emb, spec_out)

@@ -317,7 +317,7 @@ int unetrir_istft_features_f32(const float* feat, int B, int H, int W, int n_bin
 #define UNETRIR_PROF_FAMILIES 8
 enum { UNETRIR_FAM_CONV_FWD = 0, UNETRIR_FAM_CONV_DGRAD = 1, UNETRIR_FAM_CONV_WGRAD = 2,
        UNETRIR_FAM_BN = 3, UNETRIR_FAM_OTHER = 4 };
-int unetrir_prof_enable(int on);
+int unetrir_prof_enable(int on);      /* 0: off, 1: every family, 2: forward convolutions only (fewer events in the stream) */
 int unetrir_prof_collect(int* counts, double* ms, double* flops);
 
 #ifdef __cplusplus

@@ -32,11 +32,12 @@ inline bool geom_ok(const unetrir_conv_geom* g) {
 struct ProfRec { int fam; hipEvent_t e0, e1; double flops; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+unsigned g_prof_mask = ~0u;       // families that get brackets (unetrir_prof_enable(2): forward convolutions only)
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
     bool on; ProfRec r; hipStream_t s;
-    ProfScope(int fam, double flops, hipStream_t st) : on(g_prof_on), s(st) {
+    ProfScope(int fam, double flops, hipStream_t st) : on(g_prof_on && ((g_prof_mask >> fam) & 1u)), s(st) {
         if (!on) return;
         r.fam = fam; r.flops = flops;
         hipEventCreate(&r.e0); hipEventCreate(&r.e1);
@@ -446,6 +447,7 @@ int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C,
 int unetrir_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+    g_prof_mask = on == 2 ? (1u << UNETRIR_FAM_CONV_FWD) : ~0u;
     if (!g_prof_on) {
         for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
         g_prof.clear();
