@@ -129,7 +129,12 @@ class Trainer:
         eng = self.engine
         eng.training = True
         if dropout_mask is None and self.dropout:
-            dropout_mask = eng.make_dropout_mask()
+            side = getattr(eng, "wg_stream", None)
+            if side is not None and os.environ.get("UNETRIR_MASK_SIDE", "1") != "0":       # its only consumers (the information-vector branch, forward and backward) run on that stream
+                with torch.cuda.stream(side):
+                    dropout_mask = eng.make_dropout_mask()
+            else:
+                dropout_mask = eng.make_dropout_mask()
         gb = eng.B * self.world_size
         eng.forward(spec_in, emb, dropout_mask=dropout_mask, target=spec_out, global_batch=gb, alpha=self.alpha)
         if return_loss:
