@@ -33,26 +33,30 @@ class DeviceBatchPipeline:
     def __iter__(self):
         stream = torch.cuda.Stream(device=self.device)
         q = queue.Queue(maxsize=self.depth)
-        slots = [dict() for _ in range(self.depth + 1)]        # pinned staging buffers, reused round-robin
-        free = [threading.Semaphore(1) for _ in slots]
+        slots = [dict() for _ in range(self.depth + 2)]        # pinned staging buffers, reused round-robin
+        slot_ev = [None] * len(slots)                          # event after the last host->device copies out of a slot
         stop = object()
 
         def producer():
             try:
                 for i, (spec_in, emb, spec_out) in enumerate(self.source):
                     s = i % len(slots)
-                    free[s].acquire()                          # the copy that last used this slot has been consumed
+                    if slot_ev[s] is not None:                 # the copies that last read this slot have finished (waited for
+                        slot_ev[s].synchronize()               # HERE, in the producer: the training thread never blocks on a copy)
                     host = [self._to_pinned(spec_in, slots[s], "in"), self._to_pinned(emb, slots[s], "emb"),
                             self._to_pinned(spec_out, slots[s], "out")]
                     with torch.cuda.stream(stream):
                         dev = [h.to(self.device, non_blocking=True) for h in host]
+                        copied = torch.cuda.Event()
+                        copied.record(stream)
+                        slot_ev[s] = copied
                         if self.nhwc:                          # [B,H,W,2] -> contiguous [B,2,H,W]
                             dev[0] = dev[0].permute(0, 3, 1, 2).contiguous()
                             dev[2] = dev[2].permute(0, 3, 1, 2).contiguous()
                         dev[0], dev[2] = dev[0].float(), dev[2].float()
                         ev = torch.cuda.Event()
                         ev.record(stream)
-                    q.put((dev, ev, s))
+                    q.put((dev, ev))
                 q.put(stop)
             except BaseException as e:                         # surface generator errors in the consumer
                 q.put(e)
@@ -65,12 +69,11 @@ class DeviceBatchPipeline:
                 break
             if isinstance(item, BaseException):
                 raise item
-            dev, ev, s = item
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            dev, ev = item
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)                                 # a wait in the stream; the host keeps running ahead
             for t in dev:
-                t.record_stream(torch.cuda.current_stream(self.device))
-            ev.synchronize()                                   # host copy finished: the pinned slot may be refilled
-            free[s].release()
+                t.record_stream(cur)
             yield dev[0], dev[1], dev[2]
         th.join()
 
