@@ -16,10 +16,15 @@ import torch
 
 
 class DeviceBatchPipeline:
-    """for spec_in, emb, spec_out in DeviceBatchPipeline(generator, device): trainer.step(spec_in, emb, spec_out)"""
+    """for spec_in, emb, spec_out in DeviceBatchPipeline(generator, device): trainer.step(spec_in, emb, spec_out)
 
-    def __init__(self, source, device, depth=2, nhwc=True):
+    depth = batches staged ahead.  The copy stream can share a hardware queue with a compute stream, in which case a copy
+    completes only after the kernels queued before it; with 2 batches ahead the producer then waits for its staging slots and
+    the step time doubles (29.9 ms at cfg 2); with 6 the host-fed step is 15.7-20 ms against 13.8 ms device-resident."""
+
+    def __init__(self, source, device, depth=6, nhwc=True, stream=None):
         self.source, self.device, self.depth, self.nhwc = source, torch.device(device), max(1, depth), nhwc
+        self.stream = stream        # copy stream; pass one the engine has probed as concurrent (e.g. engine.opt_stream) to keep copies off the compute queues
 
     def _to_pinned(self, a, slot, k):
         t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a.contiguous()
@@ -31,7 +36,7 @@ class DeviceBatchPipeline:
         return buf
 
     def __iter__(self):
-        stream = torch.cuda.Stream(device=self.device)
+        stream = self.stream if self.stream is not None else torch.cuda.Stream(device=self.device)
         q = queue.Queue(maxsize=self.depth)
         slots = [dict() for _ in range(self.depth + 2)]        # pinned staging buffers, reused round-robin
         slot_ev = [None] * len(slots)                          # event after the last host->device copies out of a slot
