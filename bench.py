@@ -3,7 +3,12 @@
 all-reduce + Adam) on N MI355X GPUs of one node.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+N > 1: one process per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE come from the
+environment), or - when WORLD_SIZE is not set - this process starts them itself as children through the same launcher BEFORE
+touching the GPU, waits, and exits with their status (the reference is single-process multi-GPU: tf.distribute.MirroredStrategy,
+main_training.py:56, :323-327, so `bench.py --gpus 8` alone must work).
 
 Workload at every N: BASELINE.json configs[1] per GPU - dl_models/u_net.py UNet, 4 down / 4 up, number_filters_0=64,
 kernels=3, batch 32 of [2,256,256] synthetic amp/phase spectrograms + [2,16] information vectors (weak scaling: the
@@ -12,6 +17,8 @@ global batch is 32*N, configs[2] at N=8).  Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -154,6 +161,22 @@ def run_mode(U, args, dtype, world, rank, device, steps, warmup):
     return res
 
 
+def launch_ranks(n):
+    """Start n ranks of this script (one per GPU) through torch.distributed.run as a CHILD process and return its exit
+    status.  Nothing in this parent has touched the GPU (device_count() does not), and nothing is exec'ed."""
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,11 +196,16 @@ def main():
                          "parity mode is measured as well and reported under 'fp32_mode'")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU")
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if n_dev < world or local_rank >= n_dev:
+        raise SystemExit(f"bench.py rank {rank}: --gpus {world} needs {world} visible GPUs, this node shows {n_dev}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -200,7 +228,7 @@ def main():
     head_dtype = "bf16" if args.dtype in ("bf16", "both") else "f32"
     main_res = run_mode(U, args, head_dtype, world, rank, device, args.steps, args.warmup)
     f32_res = None
-    if args.dtype == "both":
+    if args.dtype == "both" and world == 1:          # the fp32 parity mode is a single-GPU side figure
         f32_res = run_mode(U, args, "f32", world, rank, device, min(args.steps, 5), min(args.warmup, 2))
     if rank != 0:
         if dist.is_initialized():

@@ -1,34 +1,61 @@
-"""Build the gfx950 shared library (C ABI of include/unetrir.h) in-tree with hipcc."""
+"""Build the gfx950 shared library (C ABI of include/unetrir.h) in-tree with hipcc.
+
+One object per translation unit (compiled in parallel, only those whose source or headers changed), then one link:
+editing a single kernel rebuilds in seconds instead of a minute."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libunetrir.so")
 SOURCES = ["igemm.hip", "api.hip", "elementwise.hip", "head.hip", "head_mfma.hip", "wgrad3x3.hip", "wgrad3x3r.hip", "wgrad3x3g.hip", "igemm_bf16.hip", "conv3x3.hip", "conv3x3r.hip", "conv3x3g.hip", "conv3x3h.hip", "upconv3x3.hip", "upconv3x3g.hip", "features.hip", "dense.hip", "stem3x3.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(os.path.dirname(HERE), "include", "unetrir.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def needs_build():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + _headers()
+    return _stale(LIB, deps)
+
+
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ):
     """hipcc cross-compiles for gfx950 without a GPU present."""
-    if not force and not needs_build():
+    if not force and lib == LIB and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
-    return LIB
+    os.makedirs(obj_dir, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(obj_dir, s[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] +
+        [os.path.join(obj_dir, s[:-4] + ".o") for s in SOURCES])
+    return lib
 
 
 if __name__ == "__main__":
