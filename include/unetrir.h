@@ -311,6 +311,18 @@ int unetrir_stft_features_f32(const float* wav, int B, int T, int n_fft, int win
 int unetrir_istft_features_f32(const float* feat, int B, int H, int W, int n_bins, int n_frames, int n_fft, int win_length,
                                int hop_length, int denormalize, float* wav, unetrir_stream_t stream);
 
+/* ---- glue that would otherwise be framework kernels inside the step.
+ * bn_inference_affine: BatchNormalization with training=False (rir_generation.py:165): scale = gamma * rsqrt(moving_var + eps),
+ *   shift = beta - moving_mean * scale into affine[2*C] (gamma / beta NULL = 1 / 0), consumed by unetrir_bn_apply_*.
+ * dropout_mask: the keep mask of Dropout(p) (dl_models/u_net.py:260), already scaled by 1/(1-p): element i of draw
+ *   (seed, step) is a fixed function of (seed, step, i) (counter-based generator), so a step is reproducible.
+ * index_to_i32: the int32 / int64 information-vector indices as the int32 array the embedding kernels read. */
+int unetrir_bn_inference_affine_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                                    float eps, int C, float* affine, unetrir_stream_t stream);
+int unetrir_dropout_mask_f32(float* mask, long long n, float p, unsigned long long seed, unsigned long long step,
+                             unetrir_stream_t stream);
+int unetrir_index_to_i32(const void* idx, int elem_bytes, long long n, int* out, unetrir_stream_t stream);
+
 /* ---- profiling hooks used by bench.py: when enabled every conv launch is bracketed by HIP
  *      events on its own stream; collect() synchronises those events and returns, per kernel
  *      family, launch count, total milliseconds and total algorithmic FLOPs. */

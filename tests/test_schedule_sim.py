@@ -1,0 +1,205 @@
+"""The PRODUCT's step schedule on CPU: UNetEngine.forward / backward, Trainer.step, the gradient-bucket hand-over, the
+bucket-wise Adam on its own stream and the data-parallel SUM all-reduce run unmodified; only the kernels (tests/cpu_ops.py,
+oracle-backed) and the stream runtime (tests/sim_runtime.py, vector clocks + race check) are stand-ins.
+
+  * single process: a full train step equals the oracle's (loss, every gradient, every parameter after Adam) in the plain
+    schedule and in the side-stream schedule, and the side-stream schedule has no unordered cross-stream access;
+  * the race check is live: removing one event wait from the schedule is detected;
+  * world_size 2 on gloo: Trainer.step on two ranks == the oracle's single-process step over the concatenated batch with
+    per-replica BatchNorm, global-batch loss normalisation and l2 / replicas (MirroredStrategy semantics,
+    main_training.py:56, :230-233, :323-327), for two consecutive steps, with buckets small enough that several all-reduces
+    and several bucket-wise Adam launches interleave with the backward pass.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+H = W = 16
+F0 = 4
+KINDS = ("unet", "graph3", "resae")     # UNetEngine (mode 0, hand schedule), UNetGraphEngine mode 3, ResAEEngine
+
+
+def _oracle(kind):
+    """(cfg, initial parameters, loss_and_grads(params, spec_in, emb, spec_out, global_batch, n_replicas)) of one model kind."""
+    from oracle import torch_ref as R, torch_resae as RA
+    if kind == "resae":
+        cfg = RA.ResAEConfig(H, W, (4, 8, 8, 8), (3, 3, 3, 3), (2, 2, 2, 2), 8, 16)
+        lg = lambda p, a, e, b, gb, nr: RA.loss_and_grads(p, a, e, b, cfg, 0.9, gb, nr, None, None)
+        return cfg, RA.init_params(cfg, randomize_all=True, dtype=np.float64), lg
+    cfg = R.Config(H, W, F0, 3, mode=3 if kind == "graph3" else 0)
+    lg = lambda p, a, e, b, gb, nr: R.loss_and_grads(p, a, e, b, cfg, 0.9, gb, nr, None, torch.float64)
+    return cfg, R.init_params(cfg, randomize_all=True, dtype=np.float64), lg
+
+
+def _oracle_steps(world, B, n_steps, lr, kind="unet"):
+    """The reference semantics on one process: per-replica gradients summed, one Adam per step."""
+    from oracle import torch_ref as R
+    cfg, params, loss_and_grads = _oracle(kind)
+    params = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    m = {k: torch.zeros(v.shape, dtype=torch.float64) for k, v in params.items()}
+    v_ = {k: torch.zeros(v.shape, dtype=torch.float64) for k, v in params.items()}
+    spec_in, emb, spec_out = R.synthetic_batch(R.Config(H, W), B * world)
+    losses, grads_first = [], None
+    for t in range(1, n_steps + 1):
+        total, loss = None, 0.0
+        for r in range(world):
+            sl = slice(r * B, (r + 1) * B)
+            l, _, _, g = loss_and_grads(params, spec_in[sl], emb[sl], spec_out[sl], B * world, world)
+            loss += l
+            total = g if total is None else {k: total[k] + g[k] for k in g}
+        if grads_first is None:
+            grads_first = total
+        losses.append(loss)
+        for k in params:
+            new, m[k], v_[k] = R.adam_update(torch.tensor(params[k]), total[k], m[k], v_[k], t, lr)
+            params[k] = new.numpy()
+    return params, grads_first, losses
+
+
+def _build(rt, B, overlap, world=1, bucket_bytes=32 << 20, kind="unet", **kw):
+    import unet_rir_amd as U
+    from oracle import torch_ref as R
+    cfg, params, _ = _oracle(kind)
+    if kind == "unet":
+        eng = U.UNetEngine(H, W, B, F0=F0, k=3, device="cpu", runtime=rt, overlap_wgrad=overlap, n_replicas=world, **kw)
+    elif kind == "graph3":
+        eng = U.UNetGraphEngine(H, W, B, F0=F0, k=3, mode=3, device="cpu", runtime=rt, n_replicas=world)
+    else:
+        eng = U.ResAEEngine(H, W, B, cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim, cfg.n_neurons,
+                            device="cpu", runtime=rt, n_replicas=world)
+    eng.load_keras_params(params)
+    tr = U.Trainer(eng, lr=1e-3, dropout=False, world_size=world, bucket_bytes=bucket_bytes)
+    return R.Config(H, W), eng, tr
+
+
+LR, N_STEPS = 1e-3, 2
+# Adam moves every entry by ~lr per step whatever its gradient's magnitude, so fp32 rounding of a near-zero gradient entry
+# shows up as a fraction of lr: parameters are compared to 2 % of the distance they can have moved (gradients are held
+# to 1e-4 of their tensor's scale separately)
+P_ATOL = 0.02 * LR * N_STEPS
+
+
+def _check_params(eng, want):
+    got = eng.export_keras_params()
+    for n, w in want.items():
+        err = float(np.abs(got[n].double().numpy() - w).max())
+        assert err <= P_ATOL, (n, err)
+
+
+@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae")])
+def test_full_step_on_the_product_schedule_matches_oracle(monkeypatch, overlap, kind):
+    import cpu_ops
+    from sim_runtime import SimRuntime
+    from oracle import torch_ref as R
+    rt = SimRuntime()
+    cpu_ops.install(monkeypatch, rt)
+    B = 2
+    cfg, eng, tr = _build(rt, B, overlap, bucket_bytes=8192, kind=kind)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
+    t = torch.tensor
+    want_p, want_g, want_l = _oracle_steps(1, B, 2, 1e-3, kind)
+    loss = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
+    assert abs(loss - want_l[0]) <= 1e-5 * abs(want_l[0])
+    got_g = eng.export_keras_grads()
+    for n, g in want_g.items():
+        e = float((got_g[n].double() - g).abs().max())
+        assert e <= 1e-4 * float(g.abs().max()) + 1e-9, (n, e)
+    loss2 = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
+    assert abs(loss2 - want_l[1]) <= 1e-5 * abs(want_l[1])
+    _check_params(eng, want_p)
+    if overlap:
+        assert len(tr.bucketer.bounds) > 3            # several buckets: Adam ran bucket by bucket beside the backward pass
+        assert rt.n_cross_stream > 50                 # ... and the schedule's event edges were what ordered it
+    else:
+        assert rt.n_cross_stream == 0
+
+
+def test_race_check_detects_a_missing_event_wait(monkeypatch):
+    """Negative control: take the 'side stream waits for the main stream' edge out of the schedule."""
+    import cpu_ops
+    from sim_runtime import RaceError, SimRuntime
+    from oracle import torch_ref as R
+    import unet_rir_amd.engine as E
+    rt = SimRuntime()
+    cpu_ops.install(monkeypatch, rt)
+    cfg, eng, tr = _build(rt, 2, True)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, 2)
+    monkeypatch.setattr(rt, "wait", lambda stream, ev: None if stream is eng.wg_stream else stream.merge(ev.clock))
+    with pytest.raises(RaceError):
+        tr.step(torch.tensor(spec_in), torch.tensor(emb), torch.tensor(spec_out))
+
+
+def test_race_check_detects_a_missing_optimizer_join(monkeypatch):
+    """Negative control: the next forward pass must wait for the bucket-wise Adam on the optimizer stream."""
+    import cpu_ops
+    from sim_runtime import RaceError, SimRuntime
+    from oracle import torch_ref as R
+    rt = SimRuntime()
+    cpu_ops.install(monkeypatch, rt)
+    cfg, eng, tr = _build(rt, 2, True)
+    spec_in, emb, spec_out = (torch.tensor(a) for a in R.synthetic_batch(cfg, 2))
+    tr.step(spec_in, emb, spec_out)
+    monkeypatch.setattr(rt, "wait", lambda stream, ev: None if stream is rt.main and "s2" in ev.clock and ev.clock.get("s2", 0) > rt.main.clock.get("s2", 0)
+                        else stream.merge(ev.clock))
+    with pytest.raises(RaceError):
+        tr.step(spec_in, emb, spec_out)
+        tr.step(spec_in, emb, spec_out)
+
+
+def _dp_worker(rank, world, port, out_path, overlap, kind):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _pytest.monkeypatch import MonkeyPatch
+        import cpu_ops
+        from sim_runtime import SimRuntime
+        from oracle import torch_ref as R
+        mpatch = MonkeyPatch()
+        rt = SimRuntime()
+        cpu_ops.install(mpatch, rt)
+        B = 2
+        cfg, eng, tr = _build(rt, B, overlap, world=world, bucket_bytes=8192, kind=kind)
+        if rank != 0:
+            eng.theta.mul_(0.5)                       # replicas must end up with rank 0's variables
+        tr.broadcast_parameters(0)
+        spec_in, emb, spec_out = R.synthetic_batch(cfg, B * world)
+        sl = slice(rank * B, (rank + 1) * B)
+        t = torch.tensor
+        losses = [tr.step(t(spec_in[sl]), t(emb[sl]), t(spec_out[sl]), return_loss=True) for _ in range(2)]
+        lt = torch.tensor(losses, dtype=torch.float64)
+        dist.all_reduce(lt)                           # strategy.reduce(SUM, per_replica_losses) (main_training.py:326)
+        torch.save({"params": {k: v.double() for k, v in eng.export_keras_params().items()}, "losses": lt,
+                    "n_all_reduce": len(rt.collectives), "n_buckets": len(tr.bucketer.bounds), "cross": rt.n_cross_stream},
+                   f"{out_path}.{rank}")
+        mpatch.undo()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae")])
+def test_two_rank_trainer_step_equals_single_process_oracle(tmp_path, overlap, kind):
+    world = 2
+    out = str(tmp_path / "dp")
+    port = 29600 + (os.getpid() % 1500) + (7 if overlap else 0) + 11 * KINDS.index(kind)
+    mp.spawn(_dp_worker, args=(world, port, out, overlap, kind), nprocs=world, join=True)
+    want_p, _, want_l = _oracle_steps(world, 2, 2, 1e-3, kind)
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in range(world):
+        assert res[r]["n_buckets"] > 3 and res[r]["n_all_reduce"] == 2 * res[r]["n_buckets"]      # one collective per bucket per step
+        for n, w in want_p.items():
+            err = float(np.abs(res[r]["params"][n].numpy() - w).max())
+            assert err <= P_ATOL, (r, n, err)
+        np.testing.assert_allclose(res[r]["losses"].numpy(), np.array(want_l), rtol=1e-5)
+    for n in want_p:                                  # replicas stay bit-identical
+        assert torch.equal(res[0]["params"][n], res[1]["params"][n]), n

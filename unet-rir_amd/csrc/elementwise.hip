@@ -935,3 +935,64 @@ int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0
 }
 
 }  // extern "C"
+
+// -------------------------------------------------------------------------------------------
+// small host-side glue moved onto the device so that a train step launches no framework kernels:
+// BatchNorm inference affine, the Dropout keep mask, the index cast of the information vector
+// -------------------------------------------------------------------------------------------
+__global__ void bn_inference_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                           const float* __restrict__ mm, const float* __restrict__ mv, float eps, int C,
+                                           float* __restrict__ affine) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float scale = (gamma ? gamma[c] : 1.f) / sqrtf(mv[c] + eps);
+    affine[c] = scale;
+    affine[C + c] = (beta ? beta[c] : 0.f) - mm[c] * scale;
+}
+
+// counter-based generator: element i of draw (seed, step) is a fixed function of (seed, step, i) - splitmix64 finaliser
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, float p, float keep_scale, unsigned long long seed,
+                                    unsigned long long step) {
+    const unsigned long long key = mix64(seed * 0x9E3779B97F4A7C15ULL + step);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = mix64(key + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1));
+        const float u = (float)(r >> 40) * (1.0f / 16777216.0f);          // 24 bits -> [0, 1)
+        mask[i] = (u >= p) ? keep_scale : 0.f;
+    }
+}
+
+__global__ void index_to_i32_kernel(const void* __restrict__ idx, int elem_bytes, long long n, int* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = elem_bytes == 8 ? (int)reinterpret_cast<const long long*>(idx)[i] : reinterpret_cast<const int*>(idx)[i];
+}
+
+extern "C" {
+
+int unetrir_bn_inference_affine_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                                    float eps, int C, float* affine, unetrir_stream_t stream) {
+    if (!moving_mean || !moving_var || !affine || C <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_inference_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, moving_mean,
+                       moving_var, eps, C, affine);
+    return (int)hipGetLastError();
+}
+
+int unetrir_dropout_mask_f32(float* mask, long long n, float p, unsigned long long seed, unsigned long long step,
+                             unetrir_stream_t stream) {
+    if (!mask || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p, 1.f / (1.f - p), seed, step);
+    return (int)hipGetLastError();
+}
+
+int unetrir_index_to_i32(const void* idx, int elem_bytes, long long n, int* out, unetrir_stream_t stream) {
+    if (!idx || !out || n <= 0 || (elem_bytes != 4 && elem_bytes != 8)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(index_to_i32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, idx, elem_bytes, n, out);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

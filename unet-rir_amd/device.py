@@ -1,0 +1,58 @@
+"""The few stream / event / collective calls the engines and the trainer make, behind one object.
+
+``HipRuntime`` is the product implementation: HIP streams and events of one MI355X through ``torch.cuda`` and RCCL
+through ``torch.distributed``.  The engines and ``Trainer`` never call ``torch.cuda`` directly, so the SAME scheduling
+code (side-stream weight gradients, deferred bucket hand-over, bucket-wise Adam on a third stream) can be driven in
+the CPU tests by a simulated runtime that checks every cross-stream dependency (tests/sim_runtime.py) - that is test
+infrastructure, not a fallback: without a GPU ``HipRuntime`` raises, and the kernels behind ``ops`` exist only as HIP code.
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipRuntime:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("unet-rir_amd needs an AMD GPU (HIP); there is no CPU fallback")
+
+    # ---- streams and events
+    def current_stream(self):
+        return torch.cuda.current_stream(self.device)
+
+    def record(self, stream=None):
+        """A new event recorded on `stream` (default: the current stream)."""
+        ev = torch.cuda.Event()
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait(self, stream, ev):
+        """Work queued on `stream` after this call runs after `ev`."""
+        stream.wait_event(ev)
+
+    def on(self, stream):
+        """Context manager: launches inside go to `stream`."""
+        return torch.cuda.stream(stream)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    def concurrent_streams(self, n):
+        from .engine import pick_concurrent_streams
+        return pick_concurrent_streams(self.device, n)
+
+    # ---- collectives (RCCL: torch.distributed backend "nccl")
+    def all_reduce_sum(self, tensor, group=None):
+        """Asynchronous SUM all-reduce ordered after the work queued on the current stream; returns a handle for wait_work."""
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def wait_work(self, work):
+        """The current stream waits for the collective (the host does not)."""
+        work.wait()
+
+    def broadcast(self, tensor, src=0, group=None):
+        dist.broadcast(tensor, src=src, group=group)
+
+    # ---- bookkeeping hooks for the simulated runtime (no-ops on hardware)
+    def touch(self, reads=(), writes=(), what=""):
+        pass

@@ -16,11 +16,10 @@ Memory layout in HBM (all fp32):
 import math
 from collections import OrderedDict
 
-import os
-
 import torch
 
 from . import _lib, ops
+from .device import HipRuntime
 from .ops import Act
 
 BN_EPS = 1e-3          # keras BatchNormalization default (dl_models/u_net.py:368)
@@ -97,10 +96,8 @@ class _SideStream:
         eng = self.eng
         if eng.wg_stream is None:
             return eng.ws
-        ev = torch.cuda.Event()
-        ev.record()
-        eng.wg_stream.wait_event(ev)
-        self.ctx = torch.cuda.stream(eng.wg_stream)
+        eng.rt.wait(eng.wg_stream, eng.rt.record())
+        self.ctx = eng.rt.on(eng.wg_stream)
         self.ctx.__enter__()
         eng._flush_ready()         # buckets whose hand-over was deferred to this event (see UNetEngine.backward.ready)
         return eng.ws_w
@@ -115,14 +112,19 @@ class UNetEngine:
     """One replica of the model for a fixed per-replica batch size B on one device."""
 
     def __init__(self, H, W, B, F0=32, k=3, depth=4, batchnorm=True, inf_vector_shape=(2, 16), s0=1, s=2,
-                 device="cuda:0", n_replicas=1, dtype="f32", overlap_wgrad=False):
+                 device="cuda:0", n_replicas=1, dtype="f32", overlap_wgrad=False, runtime=None, share=None,
+                 fused_stats=True, defer_ready=True):
+        """runtime: stream / event provider (device.HipRuntime by default; the CPU tests pass a simulated one).
+        share: another UNetEngine of the same configuration whose parameters, gradients, Adam moments, work copies and
+        BatchNorm moving statistics this engine aliases (only the activation buffers depend on the batch size)."""
+        self.rt = runtime if runtime is not None else HipRuntime(device)
         if s0 != 1 or s != 2:
             raise NotImplementedError("HIP path implements resize_factor_0=[1,1], res_factor=[2,2] (the reference defaults)")
         if dtype not in ("f32", "bf16"):
             raise ValueError("dtype must be 'f32' or 'bf16'")
         # storage type of activations and their gradients; parameters, statistics and weight gradients are always fp32
         self.dtype = dtype
-        self.fused_stats = os.environ.get("UNETRIR_FUSED_STATS", "1") != "0"     # conv-epilogue BN statistics / bias gradients (bf16)
+        self.fused_stats = bool(fused_stats)     # conv-epilogue BN statistics / bias gradients (bf16); False: separate reduction passes
         self._cst_rows, self._cst_buf = {}, None
         self._cast_table = None
         self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
@@ -151,21 +153,29 @@ class UNetEngine:
         self.n_idx = int(math.prod(self.inf_vector_shape))
         self.vec_in = self.n_idx * EMB_DIM
         self.vec_dim = self.h5 * self.w5 * VEC_CH
-        self._build_params()
+        self._shared = share._shared if share is not None else {"adam_t": 0, "t_dirty": True, "dropout_step": 0}
+        self.dropout_seed = share.dropout_seed if share is not None else (torch.initial_seed() & 0xFFFFFFFF)
+        self._mask_buf = None
+        if share is not None and (share.H, share.W, share.F0, share.k, share.depth, share.batchnorm, share.dtype, share.inf_vector_shape) != \
+                (H, W, F0, k, depth, batchnorm, dtype, self.inf_vector_shape):
+            raise ValueError("share= needs an engine of the same configuration (only the batch size may differ)")
+        self._build_params(share)
         self._alloc()
         self.ws = ops.Workspace(self.device)
         self._reserve_workspace()
         self.training = True
-        self.t_dirty = True
         self._pending_ready = []
-        self._defer_ready = os.environ.get("UNETRIR_DEFER_READY", "1") != "0"      # A/B switch
+        self._defer_ready = bool(defer_ready)    # park bucket hand-overs until the side stream next waits for the main stream
         # overlap_wgrad: weight gradients depend only on tensors the main stream has already produced, so they can run on a
         # side HIP stream (own scratch buffer) beside the dgrad -> BatchNorm-backward chain.  Measured -0.5 ms per step
         # (3 %) in bf16 at cfg 2 (scripts/overlap_ab.py, alternating engines in one process), 0 % in fp32.  bench.py turns
         # it on; the default stays off because overlapping launches make per-kernel event brackets (tests, roofline of the
         # backward kernels) ill-defined.
         # two probed streams: weight gradients, and the trainer's bucket-wise optimizer (trainer.py)
-        self.wg_stream, self.opt_stream = pick_concurrent_streams(self.device, 2) if overlap_wgrad else (None, None)
+        if share is not None and overlap_wgrad and share.wg_stream is not None:
+            self.wg_stream, self.opt_stream = share.wg_stream, share.opt_stream
+        else:
+            self.wg_stream, self.opt_stream = self.rt.concurrent_streams(2) if overlap_wgrad else (None, None)
         self.ws_w = ops.Workspace(self.device, self.ws.nbytes) if overlap_wgrad else self.ws
         self.head_direct = ops.head6x6_supported(self.ch[0])
         if self.head_direct:
@@ -174,8 +184,26 @@ class UNetEngine:
         elif self.dtype == "bf16":
             raise ValueError("the bf16 path needs number_filters_0 % 8 == 0 (direct head kernels)")
 
+    # state shared by every engine built over one parameter set (UNet keeps one engine per batch size)
+    @property
+    def adam_t(self):
+        return self._shared["adam_t"]
+
+    @adam_t.setter
+    def adam_t(self, v):
+        self._shared["adam_t"] = v
+
+    @property
+    def t_dirty(self):
+        """The work copies (transposed / bf16 kernels) are older than the master parameters."""
+        return self._shared["t_dirty"]
+
+    @t_dirty.setter
+    def t_dirty(self, v):
+        self._shared["t_dirty"] = v
+
     # ------------------------------------------------------------------ parameters
-    def _build_params(self):
+    def _build_params(self, share=None):
         k, ch, L = self.k, self.ch, self.L
         specs = []
 
@@ -224,25 +252,28 @@ class UNetEngine:
         self.specs = OrderedDict((s_.name, s_) for s_ in specs)
         self.n_flat = off
         dev = self.device
-        self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.adam_t = 0
+        if share is not None:
+            self.theta, self.grad, self.adam_m, self.adam_v = share.theta, share.grad, share.adam_m, share.adam_v
+        else:
+            self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
         self.p = {n: self.theta[s_.offset:s_.offset + s_.numel].view(s_.shape) for n, s_ in self.specs.items()}
         self.g = {n: self.grad[s_.offset:s_.offset + s_.numel].view(s_.shape) for n, s_ in self.specs.items()}
         # transposed work copies: Conv2D kernels for their data gradient, Conv2DTranspose kernels for their forward
         toff, self.tspec = 0, {}
         # the Dense kernel (49 % of the parameters) needs no transposed copy when its data gradient can read it as stored
-        self.dense_direct = os.environ.get("UNETRIR_DENSE_DGRAD", "1") != "0" and \
-            ops.dense_dgrad_supported(self.B, self.vec_in, self.vec_dim)
+        self.dense_direct = ops.dense_dgrad_supported(self.B, self.vec_in, self.vec_dim) if share is None else share.dense_direct
+        if share is not None and self.dense_direct and not ops.dense_dgrad_supported(self.B, self.vec_in, self.vec_dim):
+            raise ValueError("this batch size needs a transposed Dense kernel copy the shared parameter set does not hold")
         for n, s_ in self.specs.items():
             if s_.kind == "dense" and self.dense_direct:
                 continue
             if s_.kind in ("conv", "convT", "dense", "conv_padout"):
                 self.tspec[n] = toff
                 toff += -(-s_.numel // ALIGN) * ALIGN
-        self.theta_t = torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
+        self.theta_t = share.theta_t if share is not None else torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
         self.pt = {n: self.theta_t[o:o + self.specs[n].numel] for n, o in self.tspec.items()}
         # bf16 mode: bf16 work copies of every trunk kernel in both orientations (the information-vector branch stays fp32)
         self.ph, self.pth = {}, {}
@@ -251,16 +282,16 @@ class UNetEngine:
             for n, s_ in self.specs.items():
                 if s_.kind in ("conv", "convT", "conv_padin", "conv_padout") and not n.startswith("vec."):
                     hspec.append((n, hoff)); hoff += -(-s_.numel // ALIGN) * ALIGN
-            self.theta_h = torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
-            self.theta_th = torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
+            self.theta_h = share.theta_h if share is not None else torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
+            self.theta_th = share.theta_th if share is not None else torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
             for n, o in hspec:
                 k_ = self.specs[n].numel
                 self.ph[n] = self.theta_h[o:o + k_]
                 self.pth[n] = self.theta_th[o:o + k_]
         # BatchNorm moving statistics (non-trainable)
         self.bn_names = [n[:-len(".gamma")] for n in self.specs if n.endswith(".gamma")]
-        self.moving = {}
-        for b in self.bn_names:
+        self.moving = share.moving if share is not None else {}
+        for b in self.bn_names if share is None else ():
             c = self.specs[b + ".gamma"].numel
             self.moving[b + ".moving_mean"] = torch.zeros(c, dtype=torch.float32, device=dev)
             self.moving[b + ".moving_variance"] = torch.ones(c, dtype=torch.float32, device=dev)
@@ -389,6 +420,7 @@ class UNetEngine:
         self.pred = torch.empty((B, 2, self.H, self.W), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self.reg_out = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_tot = torch.zeros(1, dtype=torch.float32, device=dev)
         self.bn_affine = {b: torch.empty(2 * self.specs[b + ".gamma"].numel, dtype=torch.float32, device=dev) for b in self.bn_names}
         self.bn_saved = {b: torch.empty(2 * self.specs[b + ".gamma"].numel, dtype=torch.float32, device=dev) for b in self.bn_names}
         self.dropout_mask = None
@@ -472,11 +504,8 @@ class UNetEngine:
                              self.ws, self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"],
                              BN_EPS, BN_MOMENTUM)
             else:
-                c = y.C
-                rstd = torch.rsqrt(self.moving[name + ".moving_variance"] + BN_EPS)
-                scale = self.p[name + ".gamma"] * rstd
-                self.bn_affine[name][:c] = scale
-                self.bn_affine[name][c:] = self.p[name + ".beta"] - self.moving[name + ".moving_mean"] * scale
+                ops.bn_inference_affine(self.p[name + ".gamma"], self.p[name + ".beta"], self.moving[name + ".moving_mean"],
+                                        self.moving[name + ".moving_variance"], BN_EPS, self.bn_affine[name])
             ops.bn_apply(y, self.bn_affine[name], out, relu=True)
         else:
             ops.relu_fwd(y, out)
@@ -539,7 +568,9 @@ class UNetEngine:
             raise ValueError("inputs must live on the engine's device")
         if self.t_dirty or self.training:
             self.refresh_transposed()
-        self.emb_idx.copy_(emb.reshape(-1).to(torch.int32))
+        if emb.dtype not in (torch.int32, torch.int64):
+            emb = emb.to(torch.int64)
+        ops.index_to_i32(emb.contiguous(), self.emb_idx)
         self.dropout_mask = dropout_mask
 
         def vec_branch(ws_):
@@ -594,14 +625,29 @@ class UNetEngine:
             ops.sigmoid_nchw(self.logits, self.pred)
         return self.pred
 
-    def reg_loss(self):
-        """sum(model.losses) / replicas (main_training.py:232-233), evaluated on device into reg_out[0]."""
-        first = True
+    def reg_loss(self, into=None, accumulate=False):
+        """sum(model.losses) / replicas (main_training.py:232-233), evaluated on device into reg_out[0] (or added to `into`[0])."""
+        out = self.reg_out if into is None else into
+        first = not accumulate
         for n in self.l2_names:
             s_ = self.specs[n]
-            ops.sumsq(self.theta[s_.offset:s_.offset + s_.numel], L2_COEF / self.n_replicas, self.reg_out, not first, self.ws)
+            ops.sumsq(self.theta[s_.offset:s_.offset + s_.numel], L2_COEF / self.n_replicas, out, not first, self.ws)
             first = False
-        return self.reg_out
+        return out
+
+    def loss_from_logits(self, target, global_batch=None, alpha=0.9):
+        """compute_loss for the logits of the last forward pass: rewrites the prediction (same values), the data loss and
+        dL/dlogits, which seeds backward()."""
+        gb = self.B if global_batch is None else global_batch
+        if tuple(target.shape) != (self.B, 2, self.H, self.W) or target.dtype != torch.float32 or not target.is_contiguous():
+            raise ValueError(f"target must be a contiguous float32 [{self.B},2,{self.H},{self.W}] tensor")
+        ops.sigmoid_loss(self.logits, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, self.g_logits, self.loss_out, self.ws)
+
+    def loss_total(self):
+        """Data loss + l2 terms as one device scalar (a 4-byte copy and the l2 reductions accumulating onto it)."""
+        self.loss_tot.copy_(self.loss_out[0:1])
+        self.reg_loss(into=self.loss_tot, accumulate=True)
+        return self.loss_tot
 
     # ------------------------------------------------------------------ backward
     def backward(self, dpred=None, on_ready=None, include_reg=True):
@@ -630,10 +676,8 @@ class UNetEngine:
             if self._defer_ready:
                 self._pending_ready.append((on_ready, off))
                 return
-            ev = torch.cuda.Event()
-            ev.record()
-            self.wg_stream.wait_event(ev)
-            with torch.cuda.stream(self.wg_stream):
+            self.rt.wait(self.wg_stream, self.rt.record())
+            with self.rt.on(self.wg_stream):
                 on_ready(off)
 
         gl = self.g_logits
@@ -746,9 +790,7 @@ class UNetEngine:
 
     def _join_wg(self):
         if self.wg_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(self.wg_stream)
-            torch.cuda.current_stream().wait_event(ev)
+            self.rt.wait(self.rt.current_stream(), self.rt.record(self.wg_stream))
 
     # ------------------------------------------------------------------ optimizer
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
@@ -771,8 +813,17 @@ class UNetEngine:
         self.t_dirty = True
 
     def make_dropout_mask(self, generator=None):
-        keep = (torch.rand((self.B, self.vec_dim), device=self.device, generator=generator) >= DROPOUT_P)
-        return keep.to(torch.float32) / (1.0 - DROPOUT_P)
+        """Keep mask of Dropout(.3) scaled by 1/(1-p), [B, vec_dim].  Default: the HIP generator kernel, draw number
+        `dropout_step` of stream `dropout_seed` (reproducible; the trainer offsets the seed by the replica rank), written
+        into one reused buffer.  With a torch generator: torch's own stream of random numbers (tests)."""
+        if generator is not None:
+            keep = (torch.rand((self.B, self.vec_dim), device=self.device, generator=generator) >= DROPOUT_P)
+            return keep.to(torch.float32) / (1.0 - DROPOUT_P)
+        if self._mask_buf is None:
+            self._mask_buf = torch.empty((self.B, self.vec_dim), dtype=torch.float32, device=self.device)
+        ops.dropout_mask(self._mask_buf, DROPOUT_P, self.dropout_seed, self._shared["dropout_step"])
+        self._shared["dropout_step"] += 1
+        return self._mask_buf
 
     def n_params(self):
         """Trainable parameter count in the reference's sense (padding excluded)."""

@@ -12,6 +12,7 @@ from collections import OrderedDict
 import torch
 
 from . import ops
+from .device import HipRuntime
 from .ops import Act
 from .engine import ALIGN, BN_EPS, BN_MOMENTUM, L2_COEF, DROPOUT_P, ParamSpec
 
@@ -31,11 +32,16 @@ class Node:
 
 
 class GraphEngine:
-    def __init__(self, B, device="cuda:0", n_replicas=1):
+    def __init__(self, B, device="cuda:0", n_replicas=1, runtime=None):
+        self.rt = runtime if runtime is not None else HipRuntime(device)
         self.B = B
         self.device = torch.device(device)
         self.n_replicas = n_replicas
+        self.training = True
+        self.t_dirty = True          # the transposed kernel copies are older than the parameters
         self.nodes, self.specs_fwd, self.ops = [], [], []
+        self._op_params, self._n_specs_seen = [], 0
+        self.dropout_seed, self._dropout_step, self._mask_bufs = torch.initial_seed() & 0xFFFFFFFF, 0, {}
         self.bn_names, self.l2_names = [], []
         self.moving = {}
         self.masks = {}              # dropout keep masks by name (None = no dropout)
@@ -52,6 +58,12 @@ class GraphEngine:
     def _reg(self, node):
         self.nodes.append(node)
         return node
+
+    def _push(self, fwd, bwd):
+        """Append one op; the parameters declared since the previous op are the ones whose gradients its `bwd` finalises."""
+        self.ops.append((fwd, bwd))
+        self._op_params.append([s_.name for s_ in self.specs_fwd[self._n_specs_seen:]])
+        self._n_specs_seen = len(self.specs_fwd)
 
     def _new(self, h, w, c, needs_grad=True):
         return self._reg(Node(ops.new_act(self.B, h, w, c, self.device), needs_grad))
@@ -119,7 +131,7 @@ class GraphEngine:
                 self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, self._p[kname], dst, addend=add))
             else:
                 self._emit(x, lambda dst, add: ops.conv2d_dgrad(g, y.g, self._pt[kname], dst, addend=add))
-        self.ops.append((fwd, bwd))
+        self._push(fwd, bwd)
         return y
 
     def _bn_act(self, x: Node, name, act, addend: Node = None, out: Node = None, batchnorm=True):
@@ -138,8 +150,10 @@ class GraphEngine:
         gj = Act(torch.empty_like(x.a.base)) if addend is not None else None
 
         def fwd():
-            if batchnorm:
+            if batchnorm and self.training:
                 ops.bn_stats(x.a, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, self.ws, mm, mv, BN_EPS, BN_MOMENTUM)
+            elif batchnorm:          # training=False: normalise with the moving statistics
+                ops.bn_inference_affine(self._p[name + ".gamma"], self._p[name + ".beta"], mm, mv, BN_EPS, aff)
             ops.bn_act_add(x.a, aff if batchnorm else None, y.a, act, addend.a if addend is not None else None)
 
         def bwd():
@@ -159,7 +173,7 @@ class GraphEngine:
                     ops.bn_act_add(gsrc, None, x.g, 0, None)
                 self._emit(addend, lambda dst, add: ops.bn_act_add(gsrc, None, dst, 0, add))
             x.g_set = True
-        self.ops.append((fwd, bwd))
+        self._push(fwd, bwd)
         return y
 
     def _add(self, x: Node, y: Node, out: Node = None):
@@ -172,7 +186,7 @@ class GraphEngine:
         def bwd():
             self._emit(x, lambda dst, add: ops.bn_act_add(z.g, None, dst, 0, add))
             self._emit(y, lambda dst, add: ops.bn_act_add(z.g, None, dst, 0, add))
-        self.ops.append((fwd, bwd))
+        self._push(fwd, bwd)
         return z
 
     def _dense(self, x: Node, name, n_out):
@@ -197,7 +211,7 @@ class GraphEngine:
             else:
                 ops.mul(y.g.base, m, x.g.base)
             x.g_set = True
-        self.ops.append((fwd, bwd))
+        self._push(fwd, bwd)
         return y
 
     def _embedding(self, n_idx, name="embedding", vocab=2000, dim=256):
@@ -205,6 +219,7 @@ class GraphEngine:
         B, dev = self.B, self.device
         self._param(name, (vocab, dim), "embedding", (vocab, dim))
         self.emb_idx = torch.zeros(B * n_idx, dtype=torch.int32, device=dev)
+        self.n_idx = n_idx
         emb_out = torch.empty((B * n_idx, dim), dtype=torch.float32, device=dev)
         g_emb_out = torch.empty_like(emb_out)
         node = self._reg(Node(Act(emb_out.view(B, 1, 1, n_idx * dim)), True, Act(g_emb_out.view(B, 1, 1, n_idx * dim))))
@@ -214,8 +229,13 @@ class GraphEngine:
 
         def bwd():
             ops.embedding_bwd(self.emb_idx, g_emb_out, self._g[name])
-        self.ops.append((fwd, bwd))
+        self._push(fwd, bwd)
         return node
+
+    def set_indices(self, emb):
+        if emb.dtype not in (torch.int32, torch.int64):
+            emb = emb.to(torch.int64)
+        ops.index_to_i32(emb.contiguous(), self.emb_idx)
 
     def _reshape(self, x: Node, h, w, c):
         """Reshape of a [B,1,1,h*w*c] node to NHWC [B,h,w,c] (Keras Reshape is NHWC): a view, gradients alias."""
@@ -223,7 +243,7 @@ class GraphEngine:
 
         def bwd():
             x.g_set = True
-        self.ops.append((lambda: None, bwd))
+        self._push(lambda: None, bwd)
         return v
 
     # ------------------------------------------------------------------ parameters
@@ -326,13 +346,24 @@ class GraphEngine:
 
     # ------------------------------------------------------------------ step pieces
     def run_forward(self):
-        self.refresh_transposed()
+        if self.t_dirty or self.training:
+            self.refresh_transposed()
+            self.t_dirty = False
         for fwd, _ in self.ops:
             fwd()
 
-    def backward(self):
-        for _, bwd in reversed(self.ops):
+    def backward(self, on_ready=None, dpred=None):
+        """Gradients of every trainable variable into the flat gradient buffer, seeded by the loss kernel's dL/dlogits (or by an
+        upstream dL/dpred, NCHW).  The flat buffer is laid out in backward-completion order, so after an op's backward closure
+        everything up to the end of that op's parameters is final: `on_ready(offset_end)` hands that prefix to the trainer
+        (gradient bucket all-reduce, trainer.GradBucketer)."""
+        if dpred is not None:
+            ops.sigmoid_bwd(self.pred, dpred, self.logits.g)
+            self.logits.g_set = True
+        for (_, bwd), names in zip(reversed(self.ops), reversed(self._op_params)):
             bwd()
+            if on_ready is not None and names:
+                on_ready(max(self.specs[n].offset + (-(-self.specs[n].numel // ALIGN) * ALIGN) for n in names))
         for node in self.nodes:          # next step: the first writer of every gradient writes again
             node.g_set = False
 
@@ -345,31 +376,54 @@ class GraphEngine:
             ops.sigmoid_nchw(logits.a, self.pred)
         return self.pred
 
+    def loss_from_logits(self, target, global_batch=None, alpha=0.9):
+        """compute_loss for the logits of the last forward pass (seeds backward())."""
+        if tuple(target.shape) != (self.B, 2, self.H, self.W) or target.dtype != torch.float32 or not target.is_contiguous():
+            raise ValueError(f"target must be a contiguous float32 [{self.B},2,{self.H},{self.W}] tensor")
+        self.loss_or_sigmoid(self.logits, target, global_batch, alpha)
+
+    def loss_total(self):
+        self.loss_tot.copy_(self.loss_out[0:1])
+        self.reg_loss(into=self.loss_tot, accumulate=True)
+        return self.loss_tot
+
     def _alloc_outputs(self):
         dev = self.device
+        self.loss_tot = torch.zeros(1, dtype=torch.float32, device=dev)
         self.pred = torch.empty((self.B, 2, self.H, self.W), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self.reg_out = torch.zeros(1, dtype=torch.float32, device=dev)
 
-    def reg_loss(self):
-        """sum(model.losses) / replicas evaluated on device into reg_out[0]."""
-        first = True
+    def reg_loss(self, into=None, accumulate=False):
+        """sum(model.losses) / replicas evaluated on device into reg_out[0] (or added to `into`[0])."""
+        out = self.reg_out if into is None else into
+        first = not accumulate
         for n in self.l2_names:
             s_ = self.specs[n]
-            ops.sumsq(self.theta[s_.offset:s_.offset + s_.numel], L2_COEF / self.n_replicas, self.reg_out, not first, self.ws)
+            ops.sumsq(self.theta[s_.offset:s_.offset + s_.numel], L2_COEF / self.n_replicas, out, not first, self.ws)
             first = False
         if first:
-            self.reg_out.zero_()
-        return self.reg_out
+            out.zero_()
+        return out
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7):
         self.adam_t += 1
         t = self.adam_t
         ops.adam(self.theta, self.grad, self.adam_m, self.adam_v, lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t),
                  beta1, beta2, eps, 1.0)
+        self.t_dirty = True
 
-    def dropout_mask(self, n, generator=None):
-        return (torch.rand((self.B, n), device=self.device, generator=generator) >= DROPOUT_P).to(torch.float32) / (1.0 - DROPOUT_P)
+    def dropout_mask(self, n, generator=None, slot=0):
+        """Keep mask [B, n] of Dropout(.3) scaled by 1/(1-p): HIP generator kernel into a reused buffer per `slot`, or torch's
+        generator when one is passed (tests)."""
+        if generator is not None:
+            return (torch.rand((self.B, n), device=self.device, generator=generator) >= DROPOUT_P).to(torch.float32) / (1.0 - DROPOUT_P)
+        buf = self._mask_bufs.get(slot)
+        if buf is None or buf.shape[1] != n:
+            buf = self._mask_bufs[slot] = torch.empty((self.B, n), dtype=torch.float32, device=self.device)
+        ops.dropout_mask(buf, DROPOUT_P, self.dropout_seed, self._dropout_step)
+        self._dropout_step += 1
+        return buf
 
     def n_params(self):
         return sum(int(math.prod(s_.keras_shape)) for s_ in self.specs.values())

@@ -259,6 +259,12 @@ def bn_bwd(da: Act, x: Act, gamma, affine, saved, dx: Act, dgamma, dbeta, ws: Wo
               "bn_bwd")
 
 
+def bn_inference_affine(gamma, beta, moving_mean, moving_var, eps, affine):
+    """training=False: the BatchNormalization affine from the moving statistics (rir_generation.py:165)."""
+    check(_lib.lib().unetrir_bn_inference_affine_f32(_p(gamma), _p(beta), _p(moving_mean), _p(moving_var), eps, moving_mean.numel(),
+                                                     _p(affine), _stream()), "bn_inference_affine")
+
+
 def bn_act_add(x: Act, affine, y: Act, act=2, addend: Act = None):
     """BatchNormalization -> Add -> activation (dl_models/res_ae.py:331-336); act 0 none, 1 ReLU, 2 LeakyReLU(0.3)."""
     check(_lib.lib().unetrir_bn_act_add_f32(_p(x), x.ld, x.P, x.C, _p(affine), int(act), _p(addend),
@@ -391,6 +397,18 @@ def embedding_fwd(idx, table, out):
 def embedding_bwd(idx, dout, dtable):
     check(_lib.lib().unetrir_embedding_bwd_f32(_p(idx), idx.numel(), _p(dout), dtable.shape[0], dtable.shape[1],
                                                _p(dtable), _stream()), "embedding_bwd")
+
+
+def dropout_mask(mask, p, seed, step):
+    """Keep mask of Dropout(p) scaled by 1/(1-p) (dl_models/u_net.py:260), draw number `step` of stream `seed`."""
+    check(_lib.lib().unetrir_dropout_mask_f32(_p(mask), mask.numel(), float(p), int(seed), int(step), _stream()), "dropout_mask")
+
+
+def index_to_i32(idx, out):
+    """int32 / int64 index tensor -> the int32 array the embedding kernels read."""
+    if idx.dtype not in (torch.int32, torch.int64) or not idx.is_contiguous() or idx.numel() != out.numel():
+        raise ValueError("indices must be a contiguous int32 or int64 tensor of the expected size")
+    check(_lib.lib().unetrir_index_to_i32(_p(idx), idx.element_size(), idx.numel(), _p(out), _stream()), "index_to_i32")
 
 
 def mul(x, m, y):

@@ -15,8 +15,8 @@ class ResAEEngine(GraphEngine):
     """One replica of ResAE for a fixed per-replica batch size (constructor mirrors dl_models/res_ae.py:41-50)."""
 
     def __init__(self, H, W, B, conv_filters=(32, 64, 128, 256), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
-                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1):
-        super().__init__(B, device, n_replicas)
+                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None):
+        super().__init__(B, device, n_replicas, runtime)
         self.H, self.W = H, W
         self.filters, self.kernels, self.strides = tuple(conv_filters), tuple(conv_kernels), tuple(conv_strides)
         if any(f % 4 for f in self.filters) or any(s not in (1, 2) for s in self.strides):
@@ -70,7 +70,7 @@ class ResAEEngine(GraphEngine):
         def cat_bwd():
             x_last.g.base.view(B, -1).copy_(cat.g.base.view(B, -1)[:, :n_feat]); x_last.g_set = True
             vec.g.base.view(B, -1).copy_(cat.g.base.view(B, -1)[:, n_feat:]); vec.g_set = True
-        self.ops.append((cat_fwd, cat_bwd))
+        self._push(cat_fwd, cat_bwd)
         z = self._dense(cat, "e_out", self.latent)
         zd = self._dropout(z, "latent")
         d = self._dense(zd, "decoder_dense", n_feat)             # decoder: Dense -> Dropout -> Reshape (:247-268)
@@ -88,11 +88,14 @@ class ResAEEngine(GraphEngine):
         if (self.logits.a.H, self.logits.a.W) != (self.H, self.W):
             raise ValueError("decoder output size does not match the input size")
 
-    def forward(self, spec, emb, mask_latent=None, mask_dec=None, target=None, global_batch=None, alpha=0.9):
+    def forward(self, spec, emb, mask_latent=None, mask_dec=None, target=None, global_batch=None, alpha=0.9, dropout_mask=None):
+        """dropout_mask: the (latent, decoder) pair make_dropout_mask() returns (the trainer's calling convention)."""
         B = self.B
+        if dropout_mask is not None:
+            mask_latent, mask_dec = dropout_mask
         if tuple(spec.shape) != (B, 2, self.H, self.W) or spec.dtype != torch.float32 or not spec.is_contiguous():
             raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor")
-        self.emb_idx.copy_(emb.reshape(-1).to(torch.int32))
+        self.set_indices(emb)
         self.masks["latent"], self.masks["dec"] = mask_latent, mask_dec
         ops.nchw_to_nhwc_pad(spec, self.x4.a)
         self.run_forward()
@@ -100,4 +103,6 @@ class ResAEEngine(GraphEngine):
 
     def make_dropout_masks(self, generator=None):
         h, w, c = self.shape_before_bottleneck
-        return self.dropout_mask(self.latent, generator), self.dropout_mask(h * w * c, generator)
+        return self.dropout_mask(self.latent, generator, 0), self.dropout_mask(h * w * c, generator, 1)
+
+    make_dropout_mask = make_dropout_masks

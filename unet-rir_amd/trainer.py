@@ -21,13 +21,14 @@ class GradBucketer:
     (SUM) each bucket as soon as the backward pass has produced it.  Device agnostic: the same object drives RCCL
     on GPUs and gloo in the CPU tests."""
 
-    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None, reduce=True, on_bucket=None):
+    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None, reduce=True, on_bucket=None, runtime=None):
         """boundaries: increasing element offsets at which a gradient range [0, off) can become final.
         reduce=False: no collective (single replica), only the bucket schedule.  on_bucket(lo, hi, work) is called for
         every bucket right after its all-reduce has been launched (work is None without a collective): the hook the
         trainer uses to start the optimizer on finished buckets while the backward pass is still running."""
         self.flat = flat_grad
         self.group = group
+        self.rt = runtime          # device.HipRuntime (or the tests' simulated one); None: plain torch.distributed calls
         self.reduce = reduce
         self.on_bucket = on_bucket
         self.bounds = []
@@ -58,7 +59,10 @@ class GradBucketer:
             hi = self.bounds[self.next]
             work = None
             if self.reduce:
-                work = dist.all_reduce(self.flat[self.sent:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.rt is not None:
+                    work = self.rt.all_reduce_sum(self.flat[self.sent:hi], self.group)
+                else:
+                    work = dist.all_reduce(self.flat[self.sent:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self.works.append(work)
             if self.on_bucket is not None:
                 self.on_bucket(self.sent, hi, work)
@@ -68,7 +72,10 @@ class GradBucketer:
     def finish(self):
         self.mark_ready(self.flat.numel())
         for w in self.works:
-            w.wait()
+            if self.rt is not None:
+                self.rt.wait_work(w)
+            else:
+                w.wait()
         self.works = []
         self.next = 0
         self.sent = 0
@@ -81,85 +88,153 @@ def lr_schedule(lr0, epoch, decay=(True, 80)):
     return lr0
 
 
-class Trainer:
-    """Drives a UNetEngine: one call of ``step`` = one ``distributed_train_step`` of main_training.py:323-327."""
+class _LossFunction(torch.autograd.Function):
+    """compute_loss of main_training.py:203-235 as an autograd node over the engine's fused sigmoid + loss kernel: the value is
+    the per-replica scalar, backward() runs the engine's whole backward pass (and, through the trainer, the gradient
+    all-reduce and the optimizer of finished buckets)."""
 
-    def __init__(self, engine, lr=5e-7, alpha=0.9, world_size=1, group=None, bucket_bytes=32 << 20, dropout=True):
+    @staticmethod
+    def forward(ctx, trainer, anchor, loss_value):
+        ctx.trainer = trainer
+        return loss_value.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.trainer._backward_and_reduce()           # loss.backward() passes d(loss)/d(loss) = 1
+        return None, None, None
+
+
+class Trainer:
+    """One call of ``step`` = one ``distributed_train_step`` of main_training.py:323-327 on this replica.
+
+    `model` is an engine (UNetEngine, UNetGraphEngine, ResAEEngine) or a boundary module holding one (`UNet`, `ResAE`: then
+    the engine built for the module's `batch_size` is driven).  Two ways to run a step:
+
+      trainer.step(spec_in, emb, spec_out)                       # everything in one call (NCHW shards)
+
+      pred = model.model([spec_in, emb], training=True)          # the reference's own loop shape, main_training.py:253-290
+      loss = trainer.compute_loss(spec_out, pred)                #   compute_loss(spec_out, spec_generated, model.losses)
+      loss.backward()                                            #   tape.gradient  (+ all-reduce + Adam of finished buckets)
+      trainer.apply_gradients()                                  #   optimizer.apply_gradients
+    """
+
+    def __init__(self, model, lr=5e-7, alpha=0.9, world_size=1, group=None, bucket_bytes=32 << 20, dropout=True, force_dp=False):
+        """force_dp: run the bucketed all-reduce path even at world_size 1 (needs an initialised process group; rehearsal)."""
+        self.module = None
+        engine = model
+        if not hasattr(model, "specs") and hasattr(model, "engine"):
+            self.module = model
+            engine = model.engine
+            if engine is None:
+                raise RuntimeError("build the model first (batch_size=...): the trainer drives the engine of one batch size")
         self.engine = engine
+        self.rt = engine.rt
         self.lr, self.alpha = lr, alpha
         self.world_size = world_size
         self.group = group
         self.dropout = dropout
         self.bucketer = None
         engine.n_replicas = world_size
-        # UNETRIR_FORCE_DP=1 exercises the bucketed all-reduce path on a 1-rank process group (single-GPU rehearsal)
-        dp = world_size > 1 or (os.environ.get("UNETRIR_FORCE_DP") == "1" and dist.is_initialized())
+        dp = world_size > 1 or (force_dp and dist.is_initialized())
         # With a side stream in the engine (overlap_wgrad) the optimizer also leaves the critical path: Adam runs bucket by
         # bucket on a third stream as soon as a bucket's gradients are final (and, data-parallel, all-reduced), while the
         # backward pass continues.  A finished bucket's parameters are never read again by that backward pass.
         self.adam_stream = getattr(engine, "opt_stream", None) if getattr(engine, "wg_stream", None) is not None else None
         self._adam_args = None
+        self._lr_now = lr
+        self._pending = False
+        self._anchor = torch.zeros((), device=engine.device, requires_grad=True)     # makes compute_loss() a graph leaf's consumer
         if dp or self.adam_stream is not None:
             bounds = [s_.offset + (-(-s_.numel // ALIGN) * ALIGN) for s_ in engine.specs.values()]
             self.bucketer = GradBucketer(engine.grad, bounds, bucket_bytes, group, reduce=dp,
-                                         on_bucket=self._adam_bucket if self.adam_stream is not None else None)
+                                         on_bucket=self._adam_bucket if self.adam_stream is not None else None, runtime=self.rt)
 
     def broadcast_parameters(self, src=0):
         """Replicas start from identical variables (MirroredStrategy mirrors them at creation)."""
         if self.world_size > 1:
-            dist.broadcast(self.engine.theta, src=src, group=self.group)
+            self.rt.broadcast(self.engine.theta, src, self.group)
             for b in self.engine.moving.values():
-                dist.broadcast(b, src=src, group=self.group)
+                self.rt.broadcast(b, src, self.group)
             self.engine.t_dirty = True
 
     def _adam_bucket(self, lo, hi, work):
         """Adam on parameters [lo, hi) once everything queued so far on the calling stream (the engine hands buckets over
         from its side stream, which has waited for the main stream) and the bucket's all-reduce are done."""
-        eng = self.engine
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.adam_stream):
-            self.adam_stream.wait_event(ev)
+        rt = self.rt
+        ev = rt.record()
+        with rt.on(self.adam_stream):
+            rt.wait(self.adam_stream, ev)
             if work is not None:
-                work.wait()
-            eng.adam_range(lo, hi, *self._adam_args)
+                rt.wait_work(work)
+            self.engine.adam_range(lo, hi, *self._adam_args)
+
+    # ---- the three phases of a step after the forward pass
+    def _backward_and_reduce(self):
+        """tape.gradient + the cross-replica SUM (+ Adam of every bucket that is final, when the optimizer has its own stream)."""
+        eng = self.engine
+        if self.adam_stream is not None:
+            self._adam_args = eng.adam_begin(self._lr_now)
+        if self.bucketer is not None:
+            self.bucketer.reset()
+            eng.backward(on_ready=self.bucketer.mark_ready)
+        else:
+            eng.backward()
+        self._pending = True
+
+    def apply_gradients(self):
+        """optimizer.apply_gradients (main_training.py:268): waits for the all-reduce, applies Adam (the part of it that has not
+        already run bucket by bucket), joins the optimizer stream."""
+        if not self._pending:
+            raise RuntimeError("apply_gradients() without a backward pass")
+        eng, rt = self.engine, self.rt
+        if self.bucketer is not None:
+            self.bucketer.finish()              # hands over the last bucket(s); every all-reduce is waited for
+        if self.adam_stream is not None:
+            rt.wait(rt.current_stream(), rt.record(self.adam_stream))
+            eng.t_dirty = True
+        else:
+            eng.adam_step(self._lr_now)
+        self._pending = False
+
+    def _make_mask(self):
+        eng = self.engine
+        side = getattr(eng, "wg_stream", None)
+        if side is not None:       # its only consumers (the information-vector branch, forward and backward) run on that stream
+            with self.rt.on(side):
+                return eng.make_dropout_mask()
+        return eng.make_dropout_mask()
 
     def step(self, spec_in, emb, spec_out, dropout_mask=None, lr=None, return_loss=False):
         """inputs as DataGenerator.__getitem__ yields them (datageneratorv2.py:101-102), NCHW, per-replica shard."""
         eng = self.engine
         eng.training = True
         if dropout_mask is None and self.dropout:
-            side = getattr(eng, "wg_stream", None)
-            if side is not None and os.environ.get("UNETRIR_MASK_SIDE", "1") != "0":       # its only consumers (the information-vector branch, forward and backward) run on that stream
-                with torch.cuda.stream(side):
-                    dropout_mask = eng.make_dropout_mask()
-            else:
-                dropout_mask = eng.make_dropout_mask()
+            dropout_mask = self._make_mask()
         gb = eng.B * self.world_size
         eng.forward(spec_in, emb, dropout_mask=dropout_mask, target=spec_out, global_batch=gb, alpha=self.alpha)
         if return_loss:
             eng.reg_loss()                      # on the pre-update weights, as compute_loss sees them
-        lr_now = self.lr if lr is None else lr
-        if self.adam_stream is not None:
-            self._adam_args = eng.adam_begin(lr_now)
-            self.bucketer.reset()
-            eng.backward(on_ready=self.bucketer.mark_ready)
-            self.bucketer.finish()              # hands over the last bucket(s); every all-reduce is waited for on the Adam stream
-            done = torch.cuda.Event()
-            done.record(self.adam_stream)
-            torch.cuda.current_stream().wait_event(done)
-            eng.t_dirty = True
-        else:
-            if self.bucketer is not None:
-                self.bucketer.reset()
-                eng.backward(on_ready=self.bucketer.mark_ready)
-                self.bucketer.finish()
-            else:
-                eng.backward()
-            eng.adam_step(lr_now)
+        self._lr_now = self.lr if lr is None else lr
+        self._backward_and_reduce()
+        self.apply_gradients()
         if return_loss:
             return self.last_loss()
         return None
+
+    def compute_loss(self, y_true, y_pred, lr=None):
+        """compute_loss(spec_out, spec_generated, model.model.losses) of main_training.py:203-235 for the prediction the model has
+        just produced (`y_pred` must be the output of the last forward call of this trainer's model: NHWC from `model.model(...)`
+        or NCHW from `model(...)`).  Returns a differentiable 0-dim tensor: data term / global batch + l2 terms / replicas."""
+        eng = self.engine
+        if y_pred.data_ptr() != eng.pred.data_ptr():
+            raise ValueError("compute_loss needs the prediction of the model's last forward pass (its own output buffer)")
+        tgt = y_true
+        if tgt.dim() == 4 and tgt.shape[1] != 2 and tgt.shape[-1] == 2:
+            tgt = tgt.permute(0, 3, 1, 2)
+        tgt = tgt.to(eng.device, torch.float32).contiguous()
+        self._lr_now = self.lr if lr is None else lr
+        eng.loss_from_logits(tgt, eng.B * self.world_size, self.alpha)       # fused sigmoid + loss + dL/dlogits (seeds backward)
+        return _LossFunction.apply(self, self._anchor, eng.loss_total())
 
     def last_loss(self):
         """Scalar loss of the last step incl. the l2 term (host sync).  Per-replica share: SUM over replicas gives the

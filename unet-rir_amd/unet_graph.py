@@ -15,8 +15,8 @@ from .engine import VEC_CH, EMB_DIM
 
 class UNetGraphEngine(GraphEngine):
     def __init__(self, H, W, B, F0=32, k=3, depth=4, mode=0, batchnorm=True, inf_vector_shape=(2, 16), device="cuda:0",
-                 n_replicas=1):
-        super().__init__(B, device, n_replicas)
+                 n_replicas=1, runtime=None):
+        super().__init__(B, device, n_replicas, runtime)
         if mode not in (0, 1, 2, 3):
             raise ValueError("mode must be 0..3")
         if F0 % 4:
@@ -86,11 +86,14 @@ class UNetGraphEngine(GraphEngine):
         self.logits = self._conv(x, "head", 2, 6, 1, followed_by_bn=False, pad_out=4, l2=False)
         self.vec_dim = h5 * w5 * VEC_CH      # l2(0.001) sits only on the strided and the transposed convs (:274, :302)
 
+    def make_dropout_mask(self, generator=None):
+        return self.dropout_mask(self.vec_dim, generator)
+
     def forward(self, spec, emb, dropout_mask=None, target=None, global_batch=None, alpha=0.9):
         B = self.B
         if tuple(spec.shape) != (B, 2, self.H, self.W) or spec.dtype != torch.float32 or not spec.is_contiguous():
             raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor")
-        self.emb_idx.copy_(emb.reshape(-1).to(torch.int32))
+        self.set_indices(emb)
         self.masks["vec"] = dropout_mask
         ops.nchw_to_nhwc_pad(spec, self.x4.a)
         self.run_forward()
