@@ -13,6 +13,17 @@ main_training.py:56, :323-327, so `bench.py --gpus 8` alone must work).
 Workload at every N: BASELINE.json configs[1] per GPU - dl_models/u_net.py UNet, 4 down / 4 up, number_filters_0=64,
 kernels=3, batch 32 of [2,256,256] synthetic amp/phase spectrograms + [2,16] information vectors (weak scaling: the
 global batch is 32*N, configs[2] at N=8).  Prints ONE JSON line on rank 0.
+
+What the line holds besides the contract fields (N = 1):
+  roofline      the MFMA convolution kernels, HIP-event brackets on the launch stream inside the timed region: `frac` /
+                `frac_fwd` over the forward launches of the timed (side-stream) run, `frac_all` + `by_family` over forward,
+                data-gradient and weight-gradient launches of a short single-stream sub-run of the same process (with the
+                weight gradients on their own stream the backward brackets overlap and are not kernel durations)
+  module_path   the same workload driven through the drop-in boundary: UNet(nn.Module) -> model.model([spec, emb],
+                training=True) -> Trainer.compute_loss -> loss.backward() -> Trainer.apply_gradients()
+  fp32_mode     the same workload with fp32 storage (the reference's own arithmetic; the fp32-tolerance parity mode)
+  configs       one-GPU figures of the other BASELINE.json configurations (configs[3]'s model, configs[4] ResAE)
+  cpu_baseline  the CPU restatement (oracle/torch_ref.py) on this box's host cores, bounded samples
 """
 import argparse
 import json
@@ -48,11 +59,8 @@ def synthetic_batch(B, H, W, device, seed):
     return spec_in.contiguous(), emb, spec_out.contiguous()
 
 
-def cpu_baseline(F0, H, W, budget_s=45.0):
-    """The CPU restatement of the same train step (oracle/torch_ref.py, stock torch CPU ops) on this box's host cores,
-    on a bounded sample: the same model at batch 4, a few steps."""
+def _cpu_steps(F0, H, W, B, budget_s, max_steps=5):
     from oracle import torch_ref as R
-    B = 4
     cfg = R.Config(H, W, F0, 3)
     params = R.init_params(cfg)
     st = R.TrainState(cfg, params, lr=5e-7)
@@ -62,15 +70,26 @@ def cpu_baseline(F0, H, W, budget_s=45.0):
     st.step(spec_in, emb, spec_out)               # warm-up
     warm = time.time() - t0
     times = []
-    while (not times) or (sum(times) + warm + (sum(times) / len(times)) < budget_s and len(times) < 5):
+    while (not times) or (sum(times) + warm + (sum(times) / len(times)) < budget_s and len(times) < max_steps):
         t0 = time.time()
         st.step(spec_in, emb, spec_out)
         times.append(time.time() - t0)
     times.sort()
-    med = times[len(times) // 2]
-    return {"value": B / med, "unit": "spectrograms/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"same model (F0={F0}, {H}x{W}) at batch {B}, median of {len(times)} steps after 1 warm-up, "
-                      f"oracle/torch_ref.py on torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
+    return B / times[len(times) // 2], len(times)
+
+
+def cpu_baseline(F0, H, W):
+    """The CPU restatement of the same train step (oracle/torch_ref.py, stock torch CPU ops) on this box's host cores, on
+    bounded samples: the benchmarked model at batch 4, and BASELINE.json configs[0] exactly (B=4, F0=16, 256x256, fp32)."""
+    v, n = _cpu_steps(F0, H, W, 4, 30.0)
+    out = {"value": v, "unit": "spectrograms/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"same model (F0={F0}, {H}x{W}) at batch 4, median of {n} steps after 1 warm-up, "
+                     f"oracle/torch_ref.py on torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
+    v1, n1 = _cpu_steps(16, 256, 256, 4, 12.0)
+    out["cfg1"] = {"value": v1, "unit": "spectrograms/s",
+                   "sample": f"BASELINE.json configs[0] as stated: UNet base=16ch, batch=4 of [2,256,256], fp32, torch CPU; median of "
+                             f"{n1} steps after 1 warm-up"}
+    return out
 
 
 def traffic(dtype):
@@ -85,80 +104,118 @@ def traffic(dtype):
         return None, None
 
 
-def run_mode(U, args, dtype, world, rank, device, steps, warmup):
-    """Build the engine in one storage mode, run `warmup` untimed and `steps` timed train steps; returns a result dict
-    (rank 0) or None.  Timing: barrier + synchronize on both sides, MAX over ranks."""
-    H = W = args.size
-    overlap = not args.no_overlap
-    eng = U.UNetEngine(H, W, args.batch, F0=args.f0, k=3, depth=args.depth, device=device, n_replicas=world, dtype=dtype,
-                       overlap_wgrad=overlap)
-    gen = torch.Generator()
-    gen.manual_seed(0)                                   # identical initial variables on every replica
-    eng.reset_parameters(gen)
-    tr = U.Trainer(eng, lr=5e-7, alpha=0.9, world_size=world, bucket_bytes=args.bucket_mb << 20, dropout=True)
-    tr.broadcast_parameters(0)
-    spec_in, emb, spec_out = synthetic_batch(args.batch, H, W, device, 1234 + rank)
+def _fam_stats(fam, fams, dtype):
+    counts, fms, ffl = fam
+    ms, fl, nl = sum(fms[i] for i in fams), sum(ffl[i] for i in fams), sum(counts[i] for i in fams)
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return ach, ach / MFMA_PEAK_TFLOPS[dtype], ms, fl, nl
 
-    def sync():
+
+def _by_family(fam):
+    counts, fms, ffl = fam
+    return {name: {"calls": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
+            for i, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad"), (5, "stem_head_dgrad"))}
+
+
+class Runner:
+    def __init__(self, U, args, world, rank, device):
+        self.U, self.args, self.world, self.rank, self.device = U, args, world, rank, device
+
+    def sync(self):
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(device_ids=[device.index])
+        if self.world > 1:
+            dist.barrier(device_ids=[self.device.index])
             torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        tr.step(spec_in, emb, spec_out)
-    sync()
-    prof = (not args.no_prof) and rank == 0
-    if prof:
-        # overlapped schedule: only the forward brackets are clean kernel durations (see below), so only those are taken -
-        # every bracket is two event records in the stream (~8 us of dispatch gap each)
-        U.ops.prof_enable(2 if overlap and os.environ.get("UNETRIR_BENCH_PROF_ALL") != "1" else 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tr.step(spec_in, emb, spec_out)
-    sync()
-    dt = time.perf_counter() - t0
-    fam = None
-    if prof:
-        fam = U.ops.prof_collect()
-        U.ops.prof_enable(False)
-    loss = tr.last_loss()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    n_params = eng.n_params()
-    del tr, eng
-    torch.cuda.empty_cache()
-    if rank != 0:
-        return None
-    global_batch = args.batch * world
-    res = {"value": global_batch * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "dtype": dtype,
-           "loss": loss, "params": n_params}
-    if fam is not None:
-        counts, fms, ffl = fam
-        # With the weight gradients on their own stream (default) the backward brackets overlap each other, so a bracket's
-        # time is no longer the kernel's own duration: the roofline figure then comes from the FORWARD convolution launches
-        # of the same timed region, which run alone on the stream (same kernels as the data gradients).
-        fams = (0,) if overlap else (0, 1, 2)
-        conv_ms, conv_fl, nl = sum(fms[i] for i in fams), sum(ffl[i] for i in fams), sum(counts[i] for i in fams)
-        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        peak = MFMA_PEAK_TFLOPS[dtype]
-        res["roofline"] = {
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic(dtype)[0],
-            "traffic_note": traffic(dtype)[1],
-            "kernel": ("igemm_fwd_kernel / wgrad3x3_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv: fwd, dgrad, wgrad)"
-                       if dtype == "f32" else
-                       "conv3x3g / conv3x3h / upconv3x3 / igemm_fwd_bf16 (fwd, dgrad) + wgrad3x3g / wgrad3x3_bf16 (wgrad): bf16 "
-                       "v_mfma_f32_16x16x32_bf16 / 32x32x16 convolutions, fp32 accumulate") + "; layers with Cin,Cout > 8",
-            "measured_on": ("forward conv launches of the timed region (backward brackets overlap: wgrad runs on a side stream)"
-                            if overlap else "all conv launches (fwd, dgrad, wgrad) of the timed region"),
-            "calls_per_step": nl / steps, "avg_call_ms": conv_ms / max(nl, 1),
-            "algorithmic_gflop_per_step": conv_fl / steps / 1e9, "conv_ms_per_step": conv_ms / steps,
-            "by_family": {name: {"calls": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
-                          for i, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad"), (5, "stem_head_dgrad"))},
-        }
-    return res
+    def timed(self, step, steps, warmup, prof_level=0):
+        """`warmup` untimed and EXACTLY `steps` timed calls of step(); barrier + synchronize on both sides, MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        self.sync()
+        if prof_level:
+            self.U.ops.prof_enable(prof_level)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        fam = None
+        if prof_level:
+            fam = self.U.ops.prof_collect()
+            self.U.ops.prof_enable(False)
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt, fam
+
+    def engine_run(self, dtype, steps, warmup, overlap, prof=True, f0=None, size=None, depth=None, batch=None):
+        """Trainer.step over a UNetEngine.  Returns a result dict."""
+        U, a = self.U, self.args
+        f0, size, depth, batch = f0 or a.f0, size or a.size, depth or a.depth, batch or a.batch
+        eng = U.UNetEngine(size, size, batch, F0=f0, k=3, depth=depth, device=self.device, n_replicas=self.world, dtype=dtype,
+                           overlap_wgrad=overlap)
+        gen = torch.Generator()
+        gen.manual_seed(0)                                   # identical initial variables on every replica
+        eng.reset_parameters(gen)
+        eng.dropout_seed = 1234 + self.rank
+        tr = U.Trainer(eng, lr=5e-7, alpha=0.9, world_size=self.world, bucket_bytes=a.bucket_mb << 20, dropout=True,
+                       force_dp=a.force_dp)
+        tr.broadcast_parameters(0)
+        spec_in, emb, spec_out = synthetic_batch(batch, size, size, self.device, 1234 + self.rank)
+        # overlapped schedule: only the forward brackets are clean kernel durations, so only those are taken (level 2) - every
+        # bracket is two event records in the stream (~8 us of dispatch gap each)
+        level = 0 if (not prof or a.no_prof or self.rank != 0) else (2 if overlap and not a.prof_all else 1)
+        dt, fam = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, level)
+        res = {"value": batch * self.world * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup,
+               "dtype": dtype, "loss": tr.last_loss(), "params": eng.n_params(), "fam": fam, "overlap": overlap}
+        del tr, eng
+        torch.cuda.empty_cache()
+        return res
+
+    def module_run(self, dtype, steps, warmup, overlap):
+        """The same workload through the drop-in boundary (the reference's loop shape, main_training.py:253-290)."""
+        U, a = self.U, self.args
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(0)
+        model = U.UNet((a.size, a.size, 2), (2, 16), mode=0, number_filters_0=a.f0, kernels=3, name="U-Net", depth=a.depth,
+                       batch_size=a.batch, device=self.device, n_replicas=self.world, dtype=dtype, overlap=overlap)
+        torch.random.set_rng_state(gen_state)
+        model.engine.dropout_seed = 1234 + self.rank
+        tr = U.Trainer(model, lr=5e-7, alpha=0.9, world_size=self.world, bucket_bytes=a.bucket_mb << 20, force_dp=a.force_dp)
+        tr.broadcast_parameters(0)
+        spec_in, emb, spec_out = synthetic_batch(a.batch, a.size, a.size, self.device, 1234 + self.rank)
+        # DataGenerator.__getitem__ yields NHWC (datageneratorv2.py:101-102)
+        spec_in, spec_out = spec_in.permute(0, 2, 3, 1).contiguous(), spec_out.permute(0, 2, 3, 1).contiguous()
+
+        def step():
+            pred = model.model([spec_in, emb], training=True)
+            loss = tr.compute_loss(spec_out, pred)
+            loss.backward()
+            tr.apply_gradients()
+
+        dt, _ = self.timed(step, steps, warmup, 0)
+        res = {"value": a.batch * self.world * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup,
+               "loss": tr.last_loss()}
+        del tr, model
+        torch.cuda.empty_cache()
+        return res
+
+    def resae_run(self, steps, warmup):
+        """BASELINE.json configs[4]: ResAE (main_training.py:130-140: filters 32..256, k 3, s 2, latent 32, n_neurons 1024),
+        batch 32 of [2,256,256], through its boundary class and the Trainer."""
+        U = self.U
+        model = U.ResAE((256, 256, 2), (2, 16), (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 16 * 64, name="resae",
+                        batch_size=32, device=self.device)
+        tr = U.Trainer(model, lr=5e-7, alpha=0.9)
+        spec_in, emb, spec_out = synthetic_batch(32, 256, 256, self.device, 1234)
+        dt, _ = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, 0)
+        res = {"workload": "BASELINE.json configs[4]: ResAE filters (32,64,128,256), k 3, s 2, latent 32, n_neurons 1024, batch 32 of "
+                           "[2,256,256], full train step, fp32 storage", "value": 32 * steps / dt, "unit": "spectrograms/s",
+               "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "params": model.engine.n_params(), "dtype": "f32"}
+        del tr, model
+        torch.cuda.empty_cache()
+        return res
 
 
 def launch_ranks(n):
@@ -177,6 +234,43 @@ def launch_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def roofline_block(main, sub, dtype):
+    """main: the timed headline run (forward brackets when overlapped, all families otherwise); sub: optional single-stream
+    sub-run with all three families bracketed."""
+    overlap = main["overlap"]
+    fams_main = (0,) if overlap else (0, 1, 2)
+    ach, frac, ms, fl, nl = _fam_stats(main["fam"], fams_main, dtype)
+    steps = main["steps"]
+    r = {
+        "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": frac,
+        "traffic": traffic(dtype)[0], "traffic_note": traffic(dtype)[1],
+        "kernel": ("igemm_fwd_kernel / conv3x3_kernel / wgrad3x3_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv: fwd, dgrad, wgrad)"
+                   if dtype == "f32" else
+                   "conv3x3g / conv3x3h / upconv3x3g / igemm_fwd_bf16 (fwd, dgrad) + wgrad3x3g / wgrad3x3_bf16 (wgrad): bf16 "
+                   "v_mfma_f32_16x16x32_bf16 / 32x32x16 convolutions, fp32 accumulate") + "; layers with Cin,Cout > 8",
+        "measured_on": ("forward conv launches of the timed region (backward brackets overlap: wgrad runs on a side stream)"
+                        if overlap else "all conv launches (fwd, dgrad, wgrad) of the timed region"),
+        "calls_per_step": nl / steps, "avg_call_ms": ms / max(nl, 1),
+        "algorithmic_gflop_per_step": fl / steps / 1e9, "conv_ms_per_step": ms / steps,
+    }
+    if overlap:
+        r["frac_fwd"] = frac
+    if sub is not None and sub.get("fam") is not None:
+        a_all, f_all, ms_a, fl_a, nl_a = _fam_stats(sub["fam"], (0, 1, 2), dtype)
+        a_f, f_f, _, _, _ = _fam_stats(sub["fam"], (0,), dtype)
+        r["frac_all"] = f_all
+        r["single_stream_run"] = {"steps": sub["steps"], "ms_per_step": sub["ms_per_step"], "achieved_all": a_all, "frac_all": f_all,
+                                  "achieved_fwd": a_f, "frac_fwd": f_f, "calls_per_step": nl_a / sub["steps"],
+                                  "algorithmic_gflop_per_step": fl_a / sub["steps"] / 1e9, "conv_ms_per_step": ms_a / sub["steps"],
+                                  "by_family": _by_family(sub["fam"]),
+                                  "note": "weight gradients on the main stream: every bracket is one kernel's own duration"}
+    else:
+        r["by_family"] = _by_family(main["fam"])
+        if not overlap:
+            r["frac_all"] = frac
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +283,13 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-launch HIP-event bracketing of conv kernels")
+    ap.add_argument("--prof-all", action="store_true", help="bracket all three conv families in the overlapped run as well")
     ap.add_argument("--bucket-mb", type=int, default=32)
+    ap.add_argument("--force-dp", action="store_true", help="1-rank rehearsal of the bucketed RCCL all-reduce path")
+    ap.add_argument("--eager-pg", action="store_true", help="create the RCCL communicator before the engine's streams (A/B)")
+    ap.add_argument("--through-module", action="store_true",
+                    help="headline value from the drop-in boundary (UNet module + Trainer.compute_loss) instead of Trainer.step")
+    ap.add_argument("--lean", action="store_true", help="headline run only (no sub-runs, other configs or CPU baseline)")
     ap.add_argument("--dtype", choices=["bf16", "f32", "both"], default="both",
                     help="storage type of activations/gradients (accumulation, statistics, master weights are always fp32). "
                          "'both' (default): bf16 is the headline line (BASELINE.json configs[1] names bf16) and the fp32 "
@@ -210,31 +310,51 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("UNETRIR_FORCE_DP") == "1":
+    if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # No device_id: RCCL's communicator and its internal stream are then created at the first collective, AFTER the engine
         # has probed and chosen its own concurrent streams.  HIP multiplexes streams onto a few hardware queues; created first,
         # RCCL's stream can share a queue with the main or the weight-gradient stream, and its event waits (a gradient bucket
         # waiting for the backward pass) then stall every kernel queued behind them: measured 15.0-15.3 instead of 13.9 ms per
-        # step in about half of the runs (1-rank rehearsal, UNETRIR_FORCE_DP=1); created afterwards it lands on a free queue.
-        if os.environ.get("UNETRIR_BENCH_EAGER_PG") == "1":
+        # step in about half of the runs (1-rank rehearsal, --force-dp); created afterwards it lands on a free queue.
+        if args.eager_pg:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import unet_rir_amd as U
+    run = Runner(U, args, world, rank, device)
     H = W = args.size
+    overlap = not args.no_overlap
     head_dtype = "bf16" if args.dtype in ("bf16", "both") else "f32"
-    main_res = run_mode(U, args, head_dtype, world, rank, device, args.steps, args.warmup)
-    f32_res = None
-    if args.dtype == "both" and world == 1:          # the fp32 parity mode is a single-GPU side figure
-        f32_res = run_mode(U, args, "f32", world, rank, device, min(args.steps, 5), min(args.warmup, 2))
+    full = world == 1 and not args.lean              # side figures are single-GPU material
+
+    eng_res = run.engine_run(head_dtype, args.steps, args.warmup, overlap)
+    mod_res = None
+    if args.through_module or full:
+        mod_res = run.module_run(head_dtype, args.steps if args.through_module else min(args.steps, 10), min(args.warmup, 3), overlap)
+    sub = f32_res = f32_sub = None
+    configs = {}
+    if full:
+        if overlap and not args.no_prof:
+            sub = run.engine_run(head_dtype, min(args.steps, 5), 2, False)
+        if args.dtype == "both":
+            f32_res = run.engine_run("f32", min(args.steps, 5), min(args.warmup, 2), overlap)
+            f32_sub = run.engine_run("f32", 2, 1, False) if overlap and not args.no_prof else None
+        if (args.f0, args.size, args.depth, args.batch) == (64, 256, 4, 32):
+            c4 = run.engine_run("bf16", 3, 2, overlap, prof=False, f0=128, size=512, depth=5, batch=16)
+            configs["cfg4_model_1gpu"] = {
+                "workload": "BASELINE.json configs[3]'s model on ONE GPU: UNet 5 down/5 up, number_filters_0=128, kernels=3, batch 16 of "
+                            "[2,512,512], full train step, bf16 storage", "value": c4["value"], "unit": "spectrograms/s",
+                "ms_per_step": c4["ms_per_step"], "steps": c4["steps"], "warmup": c4["warmup"], "params": c4["params"], "dtype": "bf16"}
+            configs["cfg5_resae"] = run.resae_run(5, 2)
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
         return
 
+    head = mod_res if args.through_module else eng_res
     global_batch = args.batch * world
     if (args.f0, args.size, args.depth, args.batch) == (64, 256, 4, 32):
         cfg_name = "BASELINE.json configs[1]"
@@ -244,9 +364,9 @@ def main():
         cfg_name = "non-BASELINE shape"
     out = {
         "metric": "RIR spectrograms/sec (train step) on [B,2,256,256] U-Net",
-        "value": main_res["value"],
+        "value": head["value"],
         "unit": "spectrograms/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": head_dtype, "data": "synthetic",
         "config": {"workload": f"UNet {args.depth} down/{args.depth} up, number_filters_0={args.f0}, kernels=3, per-GPU batch "
@@ -254,18 +374,32 @@ def main():
                                f"{global_batch}), full train step: fwd + loss + bwd + grad all-reduce + Adam; "
                                + ("bf16 activations/gradients, fp32 accumulate/statistics/master weights" if head_dtype == "bf16"
                                   else "fp32 throughout"),
-                   "global_batch": global_batch, "parallelism": f"dp{world}", "params": main_res["params"]},
-        "loss": main_res["loss"],
+                   "global_batch": global_batch, "parallelism": f"dp{world}", "rccl_world_size": world if dist.is_initialized() else 1,
+                   "params": eng_res["params"],
+                   "driven_by": ("UNet(nn.Module).model(...) + Trainer.compute_loss/apply_gradients" if args.through_module
+                                 else "Trainer.step(UNetEngine)"),
+                   "schedule": "side-stream weight gradients + bucket-wise Adam" if overlap else "single stream"},
+        "loss": head["loss"],
     }
-    if "roofline" in main_res:
-        out["roofline"] = main_res["roofline"]
+    if eng_res.get("fam") is not None:
+        out["roofline"] = roofline_block(eng_res, sub, head_dtype)
+    if mod_res is not None:
+        out["module_path"] = {"value": mod_res["value"], "unit": "spectrograms/s", "ms_per_step": mod_res["ms_per_step"],
+                              "steps": mod_res["steps"], "warmup": mod_res["warmup"], "loss": mod_res["loss"],
+                              "vs_engine_path": mod_res["ms_per_step"] / eng_res["ms_per_step"],
+                              "note": "UNet(nn.Module, dtype, overlap) -> model.model([spec NHWC, emb], training=True) -> "
+                                      "Trainer.compute_loss -> loss.backward() -> Trainer.apply_gradients()"}
+        if args.through_module:
+            out["engine_path"] = {"value": eng_res["value"], "ms_per_step": eng_res["ms_per_step"]}
     if f32_res is not None:
         out["fp32_mode"] = {k: f32_res[k] for k in ("value", "ms_per_step", "steps", "warmup", "loss") if k in f32_res}
         out["fp32_mode"]["unit"] = "spectrograms/s"
         out["fp32_mode"]["note"] = "same workload with fp32 storage: the mode the fp32-tolerance parity tests run in"
-        if "roofline" in f32_res:
-            out["fp32_mode"]["roofline"] = f32_res["roofline"]
-    if not args.no_cpu_baseline and world == 1:
+        if f32_res.get("fam") is not None:
+            out["fp32_mode"]["roofline"] = roofline_block(f32_res, f32_sub, "f32")
+    if configs:
+        out["configs"] = configs
+    if full and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.f0, H, W)
     print(json.dumps(out))
     if dist.is_initialized():

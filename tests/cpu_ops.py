@@ -297,6 +297,16 @@ class CpuOps:
         m.copy_(m_.float()); v.copy_(v_.float())
 
 
+def _with_grad(fn):
+    """The restatements use torch.autograd for the gradient kernels; they are also called from inside an autograd backward
+    (the module path), where grad mode is off."""
+    def wrapped(*a, **k):
+        with torch.enable_grad():
+            return fn(*a, **k)
+    wrapped.__name__ = getattr(fn, "__name__", "op")
+    return wrapped
+
+
 def install(monkeypatch, rt):
     """Point every kernel-launching function of unet_rir_amd.ops at the CPU restatements (for the duration of one test)."""
     import unet_rir_amd
@@ -305,6 +315,6 @@ def install(monkeypatch, rt):
         if not name.startswith("_") and name != "rt":
             if not hasattr(unet_rir_amd.ops, name):
                 raise AttributeError(f"unet_rir_amd.ops has no function {name}")
-            monkeypatch.setattr(unet_rir_amd.ops, name, getattr(impl, name))
+            monkeypatch.setattr(unet_rir_amd.ops, name, _with_grad(getattr(impl, name)))
     monkeypatch.setattr(unet_rir_amd.ops, "bn_ws_bytes", lambda P, C_: 1 << 12)
     return impl

@@ -145,7 +145,7 @@ def test_module_dropin_autograd(U):
     ref_loss, _, ref_pred, grads = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, 0.9, B, 1, None, torch.float64)
     assert abs(float(loss.detach()) - ref_loss) <= 1e-5 * abs(ref_loss)
     named = m.named_engine_parameters()
-    # the autograd path returns data gradients; the l2 term arrives through regularization_losses()
+    # the engine's backward folds the l2 gradient in (fold_l2=True); regularization_losses() carries the values
     g = named["dec1.cb1b.kernel"].grad.permute(1, 2, 3, 0).double().cpu()
     assert float((g - grads["dec1.cb1b.kernel"]).abs().max()) <= 1e-3 * float(grads["dec1.cb1b.kernel"].abs().max())
     g = named["enc2.down.kernel"].grad.permute(1, 2, 3, 0).double().cpu()
@@ -156,8 +156,14 @@ def test_module_dropin_autograd(U):
     with torch.no_grad():
         out_eval = m.model([x.permute(0, 2, 3, 1), e], training=False)
     assert out_eval.shape == (B, H, W, 2) and bool(torch.isfinite(out_eval).all())
-    with pytest.raises(NotImplementedError):
-        U.UNet((H, W, 2), (2, 16), mode=1, batch_size=B, device=DEV)
+    # fold_l2=False: the l2 terms are differentiable torch expressions and the gradients reach .grad through autograd
+    m2 = U.UNet((H, W, 2), (2, 16), number_filters_0=F0, kernels=3, batch_size=B, device=DEV, dropout=False, fold_l2=False)
+    m2.engine.load_keras_params(Pn)
+    m2.train()
+    loss2 = R.data_loss(y, m2(x, e), 0.9, B) + sum(m2.regularization_losses())
+    loss2.backward()
+    g2 = m2.named_engine_parameters()["enc2.down.kernel"].grad.permute(1, 2, 3, 0).double().cpu()
+    assert float((g2 - grads["enc2.down.kernel"]).abs().max()) <= 1e-3 * float(grads["enc2.down.kernel"].abs().max())
 
 
 def test_depth5_graph(U):

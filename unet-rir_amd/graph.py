@@ -32,22 +32,42 @@ class Node:
 
 
 class GraphEngine:
-    def __init__(self, B, device="cuda:0", n_replicas=1, runtime=None):
+    def __init__(self, B, device="cuda:0", n_replicas=1, runtime=None, share=None):
+        """share: another engine of the same class and configuration whose parameters, gradients, Adam moments, work copies
+        and BatchNorm moving statistics this one aliases (only the activation buffers depend on the batch size)."""
         self.rt = runtime if runtime is not None else HipRuntime(device)
+        self._share = share
+        self._shared = share._shared if share is not None else {"adam_t": 0, "t_dirty": True, "dropout_step": 0}
+        self.include_reg = True       # backward adds d/dw of the l2 terms (False: the caller differentiates them itself)
         self.B = B
         self.device = torch.device(device)
         self.n_replicas = n_replicas
         self.training = True
-        self.t_dirty = True          # the transposed kernel copies are older than the parameters
         self.nodes, self.specs_fwd, self.ops = [], [], []
         self._op_params, self._n_specs_seen = [], 0
-        self.dropout_seed, self._dropout_step, self._mask_bufs = torch.initial_seed() & 0xFFFFFFFF, 0, {}
+        self.dropout_seed, self._mask_bufs = (share.dropout_seed if share is not None else torch.initial_seed() & 0xFFFFFFFF), {}
         self.bn_names, self.l2_names = [], []
         self.moving = {}
         self.masks = {}              # dropout keep masks by name (None = no dropout)
         self.ws = ops.Workspace(self.device, 1 << 20)
         self._p, self._g, self._pt = {}, {}, {}
-        self.adam_t = 0
+
+    @property
+    def adam_t(self):
+        return self._shared["adam_t"]
+
+    @adam_t.setter
+    def adam_t(self, v):
+        self._shared["adam_t"] = v
+
+    @property
+    def t_dirty(self):
+        """The transposed kernel copies are older than the parameters."""
+        return self._shared["t_dirty"]
+
+    @t_dirty.setter
+    def t_dirty(self, v):
+        self._shared["t_dirty"] = v
 
     # ------------------------------------------------------------------ construction helpers
     def _param(self, name, shape, kind, keras_shape, l2=False):
@@ -102,7 +122,7 @@ class GraphEngine:
             self._param(kname, (co, k, k, cin), kind, (cin, cout) if dense else (k, k, real_in, cout), l2)
         self._param(bname, (co,), "bias_pad" if pad_out else "bias", (cout,))
         g = ops.geom(B, x.a.H, x.a.W, cin, co, k, stride)
-        reg = lambda: (2.0 * L2_COEF / self.n_replicas) if l2 else 0.0
+        reg = lambda: (2.0 * L2_COEF / self.n_replicas) if (l2 and self.include_reg) else 0.0
 
         def dense_dgrad(dst, add):
             if add is None:      # split-K path: the weight matrix streams from every CU
@@ -144,8 +164,11 @@ class GraphEngine:
             self.bn_names.append(name)
             aff = torch.empty(2 * c, dtype=torch.float32, device=self.device)
             saved = torch.empty(2 * c, dtype=torch.float32, device=self.device)
-            mm = torch.zeros(c, dtype=torch.float32, device=self.device)
-            mv = torch.ones(c, dtype=torch.float32, device=self.device)
+            if self._share is not None:
+                mm, mv = self._share.moving[name + ".moving_mean"], self._share.moving[name + ".moving_variance"]
+            else:
+                mm = torch.zeros(c, dtype=torch.float32, device=self.device)
+                mv = torch.ones(c, dtype=torch.float32, device=self.device)
             self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"] = mm, mv
         gj = Act(torch.empty_like(x.a.base)) if addend is not None else None
 
@@ -255,17 +278,23 @@ class GraphEngine:
             off += -(-s_.numel // ALIGN) * ALIGN
         self.specs = OrderedDict((s_.name, s_) for s_ in specs)
         dev = self.device
-        self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        sh = self._share
+        if sh is not None:
+            if [(n, s_.shape) for n, s_ in sh.specs.items()] != [(n, s_.shape) for n, s_ in self.specs.items()]:
+                raise ValueError("share= needs an engine of the same configuration (only the batch size may differ)")
+            self.theta, self.grad, self.adam_m, self.adam_v = sh.theta, sh.grad, sh.adam_m, sh.adam_v
+        else:
+            self.theta = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.adam_m = torch.zeros(off, dtype=torch.float32, device=dev)
+            self.adam_v = torch.zeros(off, dtype=torch.float32, device=dev)
         for n, s_ in self.specs.items():
             self._p[n] = self.theta[s_.offset:s_.offset + s_.numel].view(s_.shape)
             self._g[n] = self.grad[s_.offset:s_.offset + s_.numel].view(s_.shape)
         self.p, self.g = self._p, self._g
         self._tnames = [n for n, s_ in self.specs.items() if s_.kind.startswith("conv")]
         toff = sum(-(-self.specs[n].numel // ALIGN) * ALIGN for n in self._tnames)
-        self.theta_t = torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
+        self.theta_t = sh.theta_t if sh is not None else torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
         o = 0
         for n in self._tnames:
             k_ = self.specs[n].numel
@@ -298,6 +327,7 @@ class GraphEngine:
                     t.zero_(); t[:2].copy_(a.to(self.device))
                 else:
                     t.copy_(a.to(self.device))
+        self.t_dirty = True
 
     def _to_keras(self, views):
         out = {}
@@ -343,20 +373,25 @@ class GraphEngine:
                     t.fill_(1.0)
                 else:
                     t.zero_()
+            for n, b in self.moving.items():
+                b.fill_(1.0 if n.endswith("variance") else 0.0)
+            self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t = 0
+        self.t_dirty = True
 
     # ------------------------------------------------------------------ step pieces
-    def run_forward(self):
+    def run_forward(self, lo=0, hi=None):
         if self.t_dirty or self.training:
             self.refresh_transposed()
             self.t_dirty = False
-        for fwd, _ in self.ops:
+        for fwd, _ in self.ops[lo:hi]:
             fwd()
 
-    def backward(self, on_ready=None, dpred=None):
+    def backward(self, on_ready=None, dpred=None, include_reg=True):
         """Gradients of every trainable variable into the flat gradient buffer, seeded by the loss kernel's dL/dlogits (or by an
         upstream dL/dpred, NCHW).  The flat buffer is laid out in backward-completion order, so after an op's backward closure
         everything up to the end of that op's parameters is final: `on_ready(offset_end)` hands that prefix to the trainer
         (gradient bucket all-reduce, trainer.GradBucketer)."""
+        self.include_reg = include_reg
         if dpred is not None:
             ops.sigmoid_bwd(self.pred, dpred, self.logits.g)
             self.logits.g_set = True
@@ -421,8 +456,8 @@ class GraphEngine:
         buf = self._mask_bufs.get(slot)
         if buf is None or buf.shape[1] != n:
             buf = self._mask_bufs[slot] = torch.empty((self.B, n), dtype=torch.float32, device=self.device)
-        ops.dropout_mask(buf, DROPOUT_P, self.dropout_seed, self._dropout_step)
-        self._dropout_step += 1
+        ops.dropout_mask(buf, DROPOUT_P, self.dropout_seed, self._shared["dropout_step"])
+        self._shared["dropout_step"] += 1
         return buf
 
     def n_params(self):

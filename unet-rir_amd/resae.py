@@ -15,8 +15,8 @@ class ResAEEngine(GraphEngine):
     """One replica of ResAE for a fixed per-replica batch size (constructor mirrors dl_models/res_ae.py:41-50)."""
 
     def __init__(self, H, W, B, conv_filters=(32, 64, 128, 256), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
-                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None):
-        super().__init__(B, device, n_replicas, runtime)
+                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None, share=None):
+        super().__init__(B, device, n_replicas, runtime, share)
         self.H, self.W = H, W
         self.filters, self.kernels, self.strides = tuple(conv_filters), tuple(conv_kernels), tuple(conv_strides)
         if any(f % 4 for f in self.filters) or any(s not in (1, 2) for s in self.strides):
@@ -73,6 +73,7 @@ class ResAEEngine(GraphEngine):
         self._push(cat_fwd, cat_bwd)
         z = self._dense(cat, "e_out", self.latent)
         zd = self._dropout(z, "latent")
+        self._latent, self._n_enc_ops = zd, len(self.ops)          # model.encoder ends here (dl_models/res_ae.py:516-530)
         d = self._dense(zd, "decoder_dense", n_feat)             # decoder: Dense -> Dropout -> Reshape (:247-268)
         dd = self._dropout(d, "dec")
         x = self._reshape(dd, h, w, c)
@@ -100,6 +101,26 @@ class ResAEEngine(GraphEngine):
         ops.nchw_to_nhwc_pad(spec, self.x4.a)
         self.run_forward()
         return self.loss_or_sigmoid(self.logits, target, global_batch, alpha)
+
+    def encode(self, spec, emb, dropout_mask=None):
+        """model.encoder([spec, emb]) (dl_models/res_ae.py:62, :391-403): the latent vector [B, latent_space_dim] (a copy)."""
+        B = self.B
+        if tuple(spec.shape) != (B, 2, self.H, self.W) or spec.dtype != torch.float32 or not spec.is_contiguous():
+            raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor")
+        self.set_indices(emb)
+        self.masks["latent"] = dropout_mask[0] if dropout_mask is not None else None
+        ops.nchw_to_nhwc_pad(spec, self.x4.a)
+        self.run_forward(0, self._n_enc_ops)
+        return self._latent.a.base.view(B, self.latent).clone()
+
+    def decode(self, z, dropout_mask=None):
+        """model.decoder(z) (dl_models/res_ae.py:63, :233-245): z [B, latent_space_dim] -> prediction [B,2,H,W] (NCHW buffer)."""
+        if tuple(z.shape) != (self.B, self.latent) or z.dtype != torch.float32:
+            raise ValueError(f"z must be float32 [{self.B},{self.latent}]")
+        self._latent.a.base.view(self.B, self.latent).copy_(z)
+        self.masks["dec"] = dropout_mask[1] if dropout_mask is not None else None
+        self.run_forward(self._n_enc_ops, None)
+        return self.loss_or_sigmoid(self.logits, None, None, 0.9)
 
     def make_dropout_masks(self, generator=None):
         h, w, c = self.shape_before_bottleneck

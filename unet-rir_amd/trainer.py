@@ -143,6 +143,7 @@ class Trainer:
         self._adam_args = None
         self._lr_now = lr
         self._pending = False
+        self._total_on_device = False
         self._anchor = torch.zeros((), device=engine.device, requires_grad=True)     # makes compute_loss() a graph leaf's consumer
         if dp or self.adam_stream is not None:
             bounds = [s_.offset + (-(-s_.numel // ALIGN) * ALIGN) for s_ in engine.specs.values()]
@@ -208,6 +209,7 @@ class Trainer:
         """inputs as DataGenerator.__getitem__ yields them (datageneratorv2.py:101-102), NCHW, per-replica shard."""
         eng = self.engine
         eng.training = True
+        self._total_on_device = False
         if dropout_mask is None and self.dropout:
             dropout_mask = self._make_mask()
         gb = eng.B * self.world_size
@@ -234,12 +236,15 @@ class Trainer:
         tgt = tgt.to(eng.device, torch.float32).contiguous()
         self._lr_now = self.lr if lr is None else lr
         eng.loss_from_logits(tgt, eng.B * self.world_size, self.alpha)       # fused sigmoid + loss + dL/dlogits (seeds backward)
+        self._total_on_device = True
         return _LossFunction.apply(self, self._anchor, eng.loss_total())
 
     def last_loss(self):
         """Scalar loss of the last step incl. the l2 term (host sync).  Per-replica share: SUM over replicas gives the
         value strategy.reduce(SUM, ...) returns (main_training.py:326)."""
         eng = self.engine
+        if self._total_on_device:                # compute_loss() path: data + l2 terms were summed on the device
+            return float(eng.loss_tot[0])
         return float(eng.loss_out[0]) + float(eng.reg_out[0])
 
 
