@@ -16,8 +16,10 @@
  *     are [Cin][kh][kw][Cout] ("IHWO"): the layout the weight-gradient kernel
  *     produces; unetrir_transpose_weight_f32 makes the other one;
  *   - Cin and Cout multiples of 4 unless stated; TF padding='same' geometry;
- *   - asynchronous on `stream`, never allocate, never synchronise, no global
- *     mutable state (thread-safe for distinct streams);
+ *   - asynchronous on `stream`, never allocate, never synchronise; thread-safe for
+ *     distinct streams.  The library holds exactly two pieces of process-global state,
+ *     both off the data path and documented where they are declared: the kernel-selection
+ *     switches (unetrir_config) and the profiling brackets (unetrir_prof_*);
  *   - return 0 on success, a hipError_t value or UNETRIR_EINVAL otherwise.
  */
 #ifndef UNETRIR_H
@@ -46,6 +48,31 @@ typedef struct {
 } unetrir_conv_geom;
 
 int unetrir_abi_version(void);
+
+/* ---- kernel-selection switches.  Several hand-written kernels can serve the same layer (e.g. a 3x3 stride-1 convolution:
+ *      tap-table implicit GEMM -> register-staged patch kernel -> LDS-DMA kernels).  The dispatch picks the most
+ *      specialised one that takes the shape; a switch set to 0 removes that kernel from the dispatch, so the layer runs on
+ *      the next more general one - for A/B measurements and for parity cross-checks between kernels.  The switches are
+ *      read ONCE, at first use, from the environment variables named below (the only variables the library reads) into
+ *      this struct; unetrir_set_config replaces the values in effect (tests, A/B scripts: process-global, not
+ *      thread-safe - call it while no launch is being issued).  Defaults: all 1.
+ *        conv3x3        UNETRIR_CONV3X3        3x3 stride-1: patch-staged kernels at all (0: tap-table implicit GEMM)
+ *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels (conv3x3g.hip)
+ *        conv3x3g_pair  UNETRIR_CONV3X3G_PAIR  its two-images-per-tile form for images <= 16 wide: 0 off, 1 when it yields
+ *                                              >= 128 workgroups, 2 whenever the shape allows
+ *        conv3x3h       UNETRIR_CONV3X3H       bf16 LDS-DMA kernel, <= 64 output channels (conv3x3h.hip)
+ *        conv3x3s       UNETRIR_CONV3X3S       bf16 strip kernel, 64 -> 64 channels, kernel resident in LDS (conv3x3s.hip)
+ *        conv3x3r       UNETRIR_CONV3X3R       bf16 register-staged row-reuse kernel (conv3x3r.hip)
+ *        stem           UNETRIR_STEM           bf16 first layer, 8 stored input channels (stem3x3.hip)
+ *        upconv3x3g     UNETRIR_UPCONV3X3G     bf16 LDS-DMA transposed / strided-dgrad kernel (upconv3x3g.hip)
+ *        wgrad3x3g      UNETRIR_WGRAD3X3G      bf16 LDS-DMA 3x3 weight gradient (wgrad3x3g.hip)
+ *        wgrad3x3r      UNETRIR_WGRAD3X3R      bf16 register-staged 3x3 weight gradient (wgrad3x3r.hip)
+ *        head_mfma      UNETRIR_HEAD_MFMA      bf16 6x6 head on the matrix cores (head_mfma.hip) */
+typedef struct {
+    int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma;
+} unetrir_config;
+int unetrir_get_config(unetrir_config* out);
+int unetrir_set_config(const unetrir_config* in);
 
 /* ---- Conv2D(padding='same'): dl_models/u_net.py:269-276 (strided, stride 1|2),
  *      :366 (3x3 block conv), :248 (6x6 head), :262 (1x1 on the information vector).
@@ -325,7 +352,8 @@ int unetrir_index_to_i32(const void* idx, int elem_bytes, long long n, int* out,
 
 /* ---- profiling hooks used by bench.py: when enabled every conv launch is bracketed by HIP
  *      events on its own stream; collect() synchronises those events and returns, per kernel
- *      family, launch count, total milliseconds and total algorithmic FLOPs. */
+ *      family, launch count, total milliseconds and total algorithmic FLOPs.  Process-global
+ *      (one mutex-protected record list); off by default; the second piece of global state. */
 #define UNETRIR_PROF_FAMILIES 8
 enum { UNETRIR_FAM_CONV_FWD = 0, UNETRIR_FAM_CONV_DGRAD = 1, UNETRIR_FAM_CONV_WGRAD = 2,
        UNETRIR_FAM_BN = 3, UNETRIR_FAM_OTHER = 4 };

@@ -1,0 +1,37 @@
+"""A/B of one kernel-selection switch on the full train step, alternating two engines in ONE process (cfg 2, bf16):
+python scripts/ab_switch.py conv3x3s [--no-overlap] [rounds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import unet_rir_amd as U
+import bench
+
+name = sys.argv[1]
+overlap = "--no-overlap" not in sys.argv
+rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 6
+dev = torch.device("cuda:0")
+trainers = {}
+for val in (1, 0):
+    U.ops.set_config(**{name: val})
+    eng = U.UNetEngine(256, 256, 32, F0=64, k=3, device=dev, dtype="bf16", overlap_wgrad=overlap)
+    g = torch.Generator(); g.manual_seed(0)
+    eng.reset_parameters(g)
+    trainers[val] = U.Trainer(eng, lr=5e-7)
+batch = bench.synthetic_batch(32, 256, 256, dev, 1234)
+res = {0: [], 1: []}
+for r in range(rounds):
+    for val in (1, 0):
+        U.ops.set_config(**{name: val})
+        tr = trainers[val]
+        for _ in range(2):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            tr.step(*batch)
+        torch.cuda.synchronize()
+        res[val].append((time.perf_counter() - t0) * 100)
+        print(f"round {r} {name}={val}: {res[val][-1]:.3f} ms/step", flush=True)
+for val in (1, 0):
+    v = sorted(res[val])
+    print(f"{name}={val}: median {v[len(v)//2]:.3f} min {v[0]:.3f} ms/step ({'overlap' if overlap else 'single stream'})")

@@ -27,3 +27,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _restore_kernel_switches():
+    """Tests may flip kernel-selection switches (ops.set_config); every test starts from and returns to the defaults."""
+    yield
+    try:
+        import unet_rir_amd
+        if unet_rir_amd._lib._LIB is not None:
+            unet_rir_amd.ops.set_config(**{n: 1 for n, _ in unet_rir_amd._lib.Config._fields_})
+    except Exception:
+        pass

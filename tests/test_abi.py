@@ -52,3 +52,23 @@ def test_product_has_no_cpu_fallback_and_does_not_import_oracle():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             unet_rir_amd.UNet((32, 32, 2), (2, 16), kernels=3, batch_size=1)
+
+
+def test_library_reads_only_the_documented_environment_switches():
+    """include/unetrir.h documents the kernel-selection switches; no other UNETRIR_* string (ablation switches, tuning
+    knobs) may be compiled into the product library, and the ablation entry point must not be exported."""
+    import subprocess
+    import unet_rir_amd
+    lib = unet_rir_amd.build.LIB
+    unet_rir_amd._lib.lib()
+    out = subprocess.run(["strings", "-n", "8", lib], capture_output=True, text=True, check=True).stdout
+    found = sorted(set(re.findall(r"UNETRIR_[A-Z0-9_]+", out)))
+    hdr = open(os.path.join(ROOT, "include", "unetrir.h")).read()
+    documented = sorted(set(re.findall(r"(UNETRIR_[A-Z0-9_]+)\s+(?:3x3|bf16|its)", hdr)))
+    assert len(documented) == 11, documented
+    assert found == documented, (found, documented)
+    assert "unetrir_abl_set" not in out
+    cfg = unet_rir_amd.ops.get_config()
+    assert sorted(cfg) == sorted(n for n, _ in unet_rir_amd._lib.Config._fields_) and all(v == 1 for v in cfg.values())
+    old = unet_rir_amd.ops.set_config(conv3x3s=0)
+    assert old["conv3x3s"] == 1 and unet_rir_amd.ops.get_config()["conv3x3s"] == 0

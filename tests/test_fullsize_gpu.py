@@ -163,8 +163,9 @@ def test_paired_tile_matches_tap_table_kernel_at_full_size(U, monkeypatch):
     w32, wh, wt = _weights(ops, C, C, 42)
     g = ops.geom(B, HW, HW, C, C, 3, 1)
     res = {}
+    monkeypatch.setattr(ops, "_restore_cfg", ops.get_config(), raising=False)
     for mode in ("1", "0"):
-        monkeypatch.setenv("UNETRIR_CONV3X3G_PAIR", mode)
+        ops.set_config(conv3x3g_pair=int(mode))
         y = ops.Act(torch.empty((B, HW, HW, C), dtype=torch.bfloat16, device=DEV))
         dx = ops.Act(torch.empty((B, HW, HW, C), dtype=torch.bfloat16, device=DEV))
         ops.conv2d_fwd(g, x, wh, None, y)
@@ -172,7 +173,7 @@ def test_paired_tile_matches_tap_table_kernel_at_full_size(U, monkeypatch):
         torch.cuda.synchronize()
         res[mode] = (y.base.float(), dx.base.float())
     assert ops.conv2d_colstat_rows(g, 0, x) == 0                   # (mode 0 is in force here: no fused statistics on that path)
-    monkeypatch.setenv("UNETRIR_CONV3X3G_PAIR", "1")
+    ops.set_config(conv3x3g_pair=1)
     assert ops.conv2d_colstat_rows(g, 0, x) == B // 2              # one statistics row per image pair
     for a, b in zip(res["1"], res["0"]):
         assert float((a - b).abs().max()) <= 2.0 ** -7 * float(a.abs().max())

@@ -323,6 +323,9 @@ BF16_CONV_CASES = [
     (2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1),            # LDS-DMA kernel (conv3x3g): ragged tiles / channels, 3 chunks
     (3, 16, 16, 64, 160, 3, 1), (4, 16, 16, 96, 128, 3, 1), (2, 32, 16, 64, 128, 3, 1), (5, 9, 11, 32, 72, 3, 1),   # conv3x3g, two narrow images per tile (odd batch, ragged)
     (2, 32, 32, 128, 256, 3, 1),                                      # LDS-DMA kernel: forward 4 chunks, data gradient 8 chunks
+    # strip kernel (conv3x3s, 64 -> 64): ragged rows and columns; many one-tile segments; whole-column strips of 3 tiles on
+    # 256 workgroups; two jobs of 2 tiles per workgroup
+    (2, 21, 60, 64, 64, 3, 1), (3, 64, 96, 64, 64, 3, 1), (16, 24, 512, 64, 64, 3, 1), (32, 16, 512, 64, 64, 3, 1),
 ]
 
 
@@ -331,7 +334,7 @@ def test_conv2d_bf16(U, case, monkeypatch):
     ops = U.ops
     B, H, W, Ci, Co, k, s = case
     if W <= 16:      # narrow images: take the paired-image tile of conv3x3g even at test sizes (it is gated on the workgroup count)
-        monkeypatch.setenv("UNETRIR_CONV3X3G_PAIR", "2")
+        ops.set_config(conv3x3g_pair=2)
     x, w, b = conv_data(case)
     x, w = q16(x), q16(w)
     x.requires_grad_(True); w.requires_grad_(True)
@@ -517,7 +520,8 @@ def test_dense_split_k(U, B, K, N):
 
 
 @pytest.mark.parametrize("case", [(2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1), (2, 30, 64, 32, 64, 3, 1), (1, 16, 32, 16, 24, 3, 1),
-                                  (5, 16, 16, 96, 128, 3, 1), (4, 24, 12, 96, 160, 3, 1)])
+                                  (5, 16, 16, 96, 128, 3, 1), (4, 24, 12, 96, 160, 3, 1),
+                                  (2, 21, 60, 64, 64, 3, 1), (3, 64, 96, 64, 64, 3, 1), (16, 24, 512, 64, 64, 3, 1)])
 def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     """Conv epilogue statistics (conv3x3g / conv3x3r<4,1>): the per-tile (sum, sum of squares) rows must add up to the
     statistics of the bf16 tensor the same launch stored, forward and data gradient, and BN statistics / bias gradients
@@ -525,7 +529,7 @@ def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     ops = U.ops
     B, H, W, Ci, Co, k, s = case
     if W <= 16:
-        monkeypatch.setenv("UNETRIR_CONV3X3G_PAIR", "2")
+        ops.set_config(conv3x3g_pair=2)
     x, w, b = conv_data(case)
     g = ops.geom(B, H, W, Ci, Co, k, s)
     xa = ops.Act(to_nhwc_bf16(q16(x), Ci, 0, DEV))
@@ -534,7 +538,10 @@ def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     ops.cast_weight_bf16(w32, wf, Co, 9, Ci, Ci)
     rows = ops.conv2d_colstat_rows(g, 0, xa)
     paired = W <= 16 and B >= 2 and Co > 64 and Ci % 32 == 0          # narrow images: two per tile
-    assert rows == ((B + 1) // 2 if paired else B) * ((H + 15) // 16) * ((W + 31) // 32)
+    if (Ci, Co) == (64, 64):          # strip kernel: one row per persistent workgroup
+        assert 0 < rows <= 256
+    else:
+        assert rows == ((B + 1) // 2 if paired else B) * ((H + 15) // 16) * ((W + 31) // 32)
     ya = ops.Act(torch.zeros((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
     cst = torch.full((rows, Co, 2), 7.0, device=DEV)
     ops.conv2d_fwd_colstat(g, xa, wf, b.float().to(DEV), ya, cst)

@@ -19,6 +19,12 @@ class CastDesc(C.Structure):
                 ("Cp", C.c_int), ("Np", C.c_int), ("reserved", C.c_int)]
 
 
+class Config(C.Structure):
+    """unetrir_config: kernel-selection switches (include/unetrir.h)."""
+    _fields_ = [(n, C.c_int) for n in ("conv3x3", "conv3x3g", "conv3x3g_pair", "conv3x3h", "conv3x3s", "conv3x3r", "stem",
+                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma")]
+
+
 class ConvGeom(C.Structure):
     """unetrir_conv_geom"""
     _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
@@ -27,6 +33,8 @@ class ConvGeom(C.Structure):
 
 _SIGS = {
     "unetrir_abi_version": (C.c_int, []),
+    "unetrir_get_config": (C.c_int, [C.POINTER(Config)]),
+    "unetrir_set_config": (C.c_int, [C.POINTER(Config)]),
     "unetrir_conv2d_fwd_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int,
                                          c_f32p, C.c_int, c_stream]),
     "unetrir_conv2d_dgrad_f32": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
@@ -154,13 +162,24 @@ class UnetrirError(RuntimeError):
     pass
 
 
+_LIB_PATH = None
+
+
+def use_library(path):
+    """Load another build of the library instead of libunetrir.so (scripts/: the timing-ablation build).  Before first use."""
+    global _LIB_PATH
+    if _LIB is not None:
+        raise UnetrirError("the library is already loaded")
+    _LIB_PATH = path
+
+
 def lib():
     """Load (building first if the sources are newer) libunetrir.so.  Raises if it cannot."""
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = _build.LIB
-    if _build.needs_build():
+    path = _LIB_PATH or _build.LIB
+    if _LIB_PATH is None and _build.needs_build():
         path = _build.build()
     if not os.path.exists(path):
         raise UnetrirError(f"HIP extension missing: {path}")

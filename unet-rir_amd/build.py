@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libunetrir.so")
-SOURCES = ["igemm.hip", "api.hip", "elementwise.hip", "head.hip", "head_mfma.hip", "wgrad3x3.hip", "wgrad3x3r.hip", "wgrad3x3g.hip", "igemm_bf16.hip", "conv3x3.hip", "conv3x3r.hip", "conv3x3g.hip", "conv3x3h.hip", "upconv3x3.hip", "upconv3x3g.hip", "features.hip", "dense.hip", "stem3x3.hip"]
+SOURCES = ["igemm.hip", "api.hip", "elementwise.hip", "head.hip", "head_mfma.hip", "wgrad3x3.hip", "wgrad3x3r.hip", "wgrad3x3g.hip", "igemm_bf16.hip", "conv3x3.hip", "conv3x3r.hip", "conv3x3g.hip", "conv3x3h.hip", "conv3x3s.hip", "upconv3x3.hip", "upconv3x3g.hip", "features.hip", "dense.hip", "stem3x3.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -58,5 +58,17 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, obj_dir=OBJ):
     return lib
 
 
+ABL_LIB = os.path.join(HERE, "libunetrir_abl.so")
+
+
+def build_ablations(verbose=False):
+    """The timing-ablation build for scripts/ (kernels with a stage switched off; results invalid).  Not loaded by the package
+    unless a script asks for it with _lib.use_library(build.ABL_LIB)."""
+    return build(force=False, verbose=verbose, extra_flags=["-DUNETRIR_ABLATIONS"], lib=ABL_LIB, obj_dir=os.path.join(HERE, "build_abl"))
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--ablations" in sys.argv:
+        print(build_ablations(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -5,6 +5,49 @@
 #include <vector>
 #include "kernels.h"
 
+// ---- kernel-selection switches: the only environment variables the library reads, once, into one struct ----
+namespace {
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+unetrir_config load_config() {
+    unetrir_config c;
+    c.conv3x3 = env_int("UNETRIR_CONV3X3", 1);
+    c.conv3x3g = env_int("UNETRIR_CONV3X3G", 1);
+    c.conv3x3g_pair = env_int("UNETRIR_CONV3X3G_PAIR", 1);
+    c.conv3x3h = env_int("UNETRIR_CONV3X3H", 1);
+    c.conv3x3s = env_int("UNETRIR_CONV3X3S", 1);
+    c.conv3x3r = env_int("UNETRIR_CONV3X3R", 1);
+    c.stem = env_int("UNETRIR_STEM", 1);
+    c.upconv3x3g = env_int("UNETRIR_UPCONV3X3G", 1);
+    c.wgrad3x3g = env_int("UNETRIR_WGRAD3X3G", 1);
+    c.wgrad3x3r = env_int("UNETRIR_WGRAD3X3R", 1);
+    c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
+    return c;
+}
+unetrir_config& config_storage() {
+    static unetrir_config c = load_config();
+    return c;
+}
+}  // namespace
+const unetrir_config& unetrir_cfg() { return config_storage(); }
+extern "C" int unetrir_get_config(unetrir_config* out) {
+    if (!out) return UNETRIR_EINVAL;
+    *out = config_storage();
+    return 0;
+}
+extern "C" int unetrir_set_config(const unetrir_config* in) {
+    if (!in) return UNETRIR_EINVAL;
+    config_storage() = *in;
+    return 0;
+}
+
+#ifdef UNETRIR_ABLATIONS
+int g_unetrir_abl = 0;
+extern "C" int unetrir_abl_set(int v) { g_unetrir_abl = v; return 0; }
+#endif
+
 namespace {
 
 struct Same { int out, before; };
@@ -61,10 +104,9 @@ inline int conv_family(const unetrir_conv_geom* g, int fam) {
 
 // element-type policies: fp32 and bf16-storage variants share the tap-table construction
 // 3x3 stride-1 layers go to the patch-staged kernel (conv3x3.hip) when its 8 x 32 pixel tiles cover the image well
-// (UNETRIR_CONV3X3=0 forces the tap-table kernels, for A/B measurements)
+// (config switch conv3x3 = 0 forces the tap-table kernels, for A/B measurements)
 inline bool use_conv3x3(int k, int stride, int H, int W) {
-    static const bool enabled = [] { const char* e = getenv("UNETRIR_CONV3X3"); return !(e && e[0] == '0'); }();
-    if (!enabled || k != 3 || stride != 1) return false;
+    if (!unetrir_cfg().conv3x3 || k != 3 || stride != 1) return false;
     const double util = (double)H * W / ((double)((H + 7) / 8 * 8) * ((W + 31) / 32 * 32));
     return util >= 0.7;
 }
@@ -83,10 +125,7 @@ struct BF16 {
     using T = __bf16; using Args = IgemmArgsH;
     static int launch(const Args& a, hipStream_t s) { return launch_igemm_fwd_bf16(a, s); }
     static int launch_classes(const Args* a, hipStream_t s) {
-        static const bool batched = [] { const char* e = getenv("UNETRIR_PARITY_X4"); return !(e && e[0] == '0'); }();
-        if (batched) return launch_igemm_fwd_bf16_x4(a, s);
-        for (int i = 0; i < 4; ++i) { const int err = launch_igemm_fwd_bf16(a[i], s); if (err) return err; }
-        return 0;
+        return launch_igemm_fwd_bf16_x4(a, s);          // the four parity classes share one grid
     }
 };
 
@@ -99,8 +138,7 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
         c.colstat = colstat;
         c.in = x; c.ldi = ldx; c.w = w; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = y; c.ldo = ldy;
         c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout;
-        static const int nostore = [] { const char* e = getenv("UNETRIR_CONV3X3_NOSTORE"); return (e && e[0] == '1') ? 2 : 0; }();
-        c.flip = nostore;
+        c.flip = UNETRIR_ABL(UNETRIR_ABL_HOST(), 256) ? 2 : 0;      // ablation build only: register-staged kernel without its stores
         // narrow images (the 16 x 16 level) would half-fill the 32-column tiles: bf16 has a paired-image tile for them
         if (use_conv3x3(g->k, g->stride, g->H, g->W) || (P::is_bf16 && conv3x3g_pair_applies(c))) return launch_conv3x3(c, P::is_bf16, s);
     }
@@ -151,7 +189,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
         c.in = dy; c.ldi = lddy; c.w = wt; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = dx; c.ldo = lddx;
         c.B = g->B; c.H = sy.out; c.W = sx.out; c.C = g->Cout; c.N = g->Cin; c.flip = 0;
         // half-empty tiles (16-wide coarse grids) stay on the four tap-table launches: measured 0.2 ms/step faster than this kernel there
-        static const double min_util = [] { const char* e = getenv("UNETRIR_UPG_MIN_UTIL"); return e ? atof(e) : 0.7; }();
+        const double min_util = 0.7;
         const double util = (double)c.H * c.W / ((double)((c.H + 7) / 8 * 8) * ((c.W + 31) / 32 * 32));
         if (use_conv3x3(3, 1, sy.out, sx.out) || (P::is_bf16 && upconv3x3g_applies(c) && util >= min_util))
             return launch_upconv3x3(c, P::is_bf16, s);
@@ -335,6 +373,7 @@ static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) 
     c.C = dgrad ? g->Cout : g->Cin; c.N = dgrad ? g->Cin : g->Cout; c.flip = dgrad ? 1 : 0;
     if (conv3x3g_pair_applies(c)) return conv3x3g_colstat_rows(c);          // two images per tile row
     if (!use_conv3x3(g->k, g->stride, g->H, g->W) || !conv3x3_has_colstat(c)) return 0;
+    if (conv3x3s_applies(c)) return conv3x3s_colstat_rows(c);               // one row per persistent workgroup
     return (long long)g->B * ((g->H + 15) / 16) * ((g->W + 31) / 32);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }

@@ -260,20 +260,18 @@ static int launch_conv3x3_t(const Conv3Args& a, hipStream_t s) {
 
 // true when launch_conv3x3(a, bf16 = 1) lands on a kernel with the fused column statistics (conv3x3g, conv3x3r<4,1>)
 bool conv3x3_has_colstat(const Conv3Args& a) {
-    static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
-    static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
+    const bool rowreuse = unetrir_cfg().conv3x3r != 0, dma = unetrir_cfg().conv3x3g != 0;
     if (dma && conv3x3g_applies(a)) return true;
-    if (conv3x3h_applies(a)) return true;
+    if (conv3x3s_applies(a) || conv3x3h_applies(a)) return true;
     return rowreuse && a.N <= 64 && !(a.flip & 2);
 }
 
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
-    // bf16: the row-reuse kernel (conv3x3r.hip) unless UNETRIR_CONV3X3R=0 or a timing experiment asks for the no-store variant
-    static const bool rowreuse = [] { const char* e = getenv("UNETRIR_CONV3X3R"); return !(e && e[0] == '0'); }();
-    static const bool dma = [] { const char* e = getenv("UNETRIR_CONV3X3G"); return !(e && e[0] == '0'); }();
-    static const bool stem = [] { const char* e = getenv("UNETRIR_STEM"); return !(e && e[0] == '0'); }();
+    // bf16: the row-reuse kernel (conv3x3r.hip) unless the conv3x3r switch is off or a timing ablation asks for the no-store variant
+    const bool rowreuse = unetrir_cfg().conv3x3r != 0, dma = unetrir_cfg().conv3x3g != 0, stem = unetrir_cfg().stem != 0;
     if (bf16 && stem && stem3x3_applies(a)) return launch_stem3x3_bf16(a, s);          // first layer: 8 stored channels -> 64
     if (bf16 && dma && conv3x3g_applies(a)) return launch_conv3x3g_bf16(a, s);
+    if (bf16 && conv3x3s_applies(a)) return launch_conv3x3s_bf16(a, s);
     if (bf16 && conv3x3h_applies(a)) return launch_conv3x3h_bf16(a, s);
     if (bf16 && rowreuse && !(a.flip & 2)) return launch_conv3x3r_bf16(a, s);
     return bf16 ? launch_conv3x3_t<__bf16>(a, s) : launch_conv3x3_t<float>(a, s);

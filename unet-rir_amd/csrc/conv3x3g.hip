@@ -400,11 +400,10 @@ bool conv3x3g_applies(const Conv3Args& a) {
 
 // images at most 16 pixels wide: the paired-image tile (full tiles where the 32-column tile would be half empty)
 bool conv3x3g_pair_applies(const Conv3Args& a) {
-    // UNETRIR_CONV3X3G_PAIR: 0 = off, 2 = whenever the shape allows (tests), default = only when the paired tiles still give at
-    // least 128 workgroups (1024 -> 1024 at 16 x 16, batch 32: 190 us against 219 us for the tap-table kernel; 512 -> 512 has
-    // 64 workgroups and loses 95 : 85).  Read on every call so that a test can switch it.
-    const char* e = getenv("UNETRIR_CONV3X3G_PAIR");
-    const int mode = e ? atoi(e) : 1;
+    // config switch conv3x3g_pair: 0 = off, 2 = whenever the shape allows (tests), 1 (default) = only when the paired tiles still
+    // give at least 128 workgroups (1024 -> 1024 at 16 x 16, batch 32: 190 us against 219 us for the tap-table kernel; 512 -> 512
+    // has 64 workgroups and loses 95 : 85)
+    const int mode = unetrir_cfg().conv3x3g_pair;
     const size_t pair_bytes = (((size_t)2 * a.H * a.W - 1) * a.ldi + a.C) * 2;
     if (mode == 0 || !conv3x3g_applies(a) || a.W > 16 || a.B < 2 || pair_bytes >= 0x70000000u) return false;
     const long long wgs = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR) * ((a.N + GBN - 1) / GBN);
@@ -423,12 +422,6 @@ int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
         return (int)hipGetLastError();
     }
     const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);
-    static const int var = [] { const char* e = getenv("UNETRIR_G_VAR"); return e ? atoi(e) : 2; }();
-    // UNETRIR_G_VAR=30: timing ablation (no DMA, no vmcnt wait, no barrier in the K loop; results invalid): measured 102 us vs
-    // 120 us for 512->512 @ 32x32, i.e. the synchronisation and staging cost 15 %, the rest is fragment reads + MFMA issue.
-    if (var == 30) hipLaunchKernelGGL(conv3x3g_bf16_kernel<30>, dim3((unsigned)tiles), dim3(512), 0, s, a);
-    else if (var & 2) hipLaunchKernelGGL(conv3x3g_bf16_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, a);
-    else if (var & 1) hipLaunchKernelGGL(conv3x3g_bf16_kernel<1>, dim3((unsigned)tiles), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(conv3x3g_bf16_kernel<0>, dim3((unsigned)tiles), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(conv3x3g_bf16_kernel<2>, dim3((unsigned)tiles), dim3(512), 0, s, a);
     return (int)hipGetLastError();
 }

@@ -307,18 +307,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3h_bf16_kernel(const Conv3Args a
 }
 
 bool conv3x3h_applies(const Conv3Args& a) {
-    static const bool on = [] { const char* e = getenv("UNETRIR_CONV3X3H"); return !(e && e[0] == '0'); }();
+    const bool on = unetrir_cfg().conv3x3h != 0;
     const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2, w_bytes = (size_t)a.N * 9 * a.C * 2;
     return on && a.C % 32 == 0 && a.N <= 64 && !(a.flip & 2) && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
 }
 
 int launch_conv3x3h_bf16(const Conv3Args& a, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + HTR - 1) / HTR) * ((a.W + 31) / 32);
-    static const int cap = [] { const char* e = getenv("UNETRIR_H_GRID"); return e ? atoi(e) : 512; }();   // 2 persistent workgroups per CU
-    static const int abl = [] { const char* e = getenv("UNETRIR_H_ABL"); return e ? atoi(e) : 0; }();
+    const int cap = 512;                                  // 2 persistent workgroups per CU
     const dim3 grid((unsigned)(tiles < cap ? tiles : cap));
-    if (abl == 1) hipLaunchKernelGGL(conv3x3h_bf16_kernel<1>, grid, dim3(256), 0, s, a);
-    else if (abl == 3) hipLaunchKernelGGL(conv3x3h_bf16_kernel<3>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv3x3h_bf16_kernel<0>, grid, dim3(256), 0, s, a);
+#ifdef UNETRIR_ABLATIONS
+    const int abl = (UNETRIR_ABL_HOST() >> 4) & 3;        // ablation build: bits 4, 5 = no DMA in the K loop / no vmcnt wait and barrier
+    if (abl == 1) { hipLaunchKernelGGL(conv3x3h_bf16_kernel<1>, grid, dim3(256), 0, s, a); return (int)hipGetLastError(); }
+    if (abl == 3) { hipLaunchKernelGGL(conv3x3h_bf16_kernel<3>, grid, dim3(256), 0, s, a); return (int)hipGetLastError(); }
+#endif
+    hipLaunchKernelGGL(conv3x3h_bf16_kernel<0>, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

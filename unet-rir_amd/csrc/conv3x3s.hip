@@ -1,0 +1,386 @@
+// conv3x3s.hip - bf16 3x3 stride-1 'same' convolution (forward / data gradient) for the 64 -> 64 channel full-resolution
+// layers of the U-Net (enc1.cb1, dec1.cb1b and their data gradients: dl_models/u_net.py:366): the HBM-bound end of the
+// 3x3 family (537 MB moved per 155 GFLOP at batch 32, 256 x 256).
+//
+// What bounds these layers is bytes in flight, not MFMA rate, so the kernel is built around the memory system:
+//   * one persistent workgroup per CU (8 waves) walks DOWN a 32-pixel-wide column strip of one image, 8 rows per tile;
+//   * the whole 64 x 9 x 64 kernel (73.7 KB bf16) is loaded into LDS ONCE per workgroup, stored in MFMA-fragment order
+//     (72 blocks of 1 KB: a fragment read is lane-linear, conflict-free, one instruction);
+//   * a pixel's 64 channels are one 128-byte line: the (8+2) x 34 pixel patch of a tile is staged by LDS-DMA in WHOLE lines
+//     (buffer_load_dwordx4 ... lds, 8 pixels per wave-instruction), each line requested once - no partial-line requests at
+//     different times (the 2.0x read over-fetch of the half-chunk kernel, conv3x3h.hip);
+//   * two patch buffers: the patch of tile t+1 streams in during the WHOLE K loop of tile t (43 KB in flight per CU, issued
+//     one instruction per K step), and its two halo rows shared with tile t are copied LDS -> LDS instead of fetched again,
+//     so the input is read 34/32 times in total;
+//   * with kernel and patch resident there is no dependency inside a tile: the K loop (2 chunks x 3 horizontal taps, 24
+//     v_mfma_f32_16x16x32_bf16 and 16 fragment reads per step and wave) runs without barriers or counted waits; ONE
+//     s_barrier per tile, in front of it a counted vmcnt that leaves the tile's output stores in flight;
+//   * a wave owns 2 rows x 16 columns x all 64 channels; the channel order inside the MFMA rows is permuted so that a lane
+//     ends up with 2 x 8 consecutive channels of one pixel: stores are 16 bytes per lane straight from registers (no LDS
+//     staging), 64-byte half lines per pixel per instruction;
+//   * fused column statistics (BatchNormalization batch statistics / bias gradients from the stored bf16 values) are
+//     accumulated per lane over ALL tiles of the workgroup and reduced once: one colstat row per workgroup.
+// Patch LDS image: pixel-major, 128-byte pixels, the eight 16-byte granules of a pixel XOR-swizzled with (column & 7) on
+// the DMA source side and on the fragment read (conflict-free ds_read_b128 for 16 consecutive columns).
+// Requires C == 64 and N == 64 (conv3x3s_applies); everything else stays on conv3x3h / conv3x3g / conv3x3r.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MMA16(accv, wfrag, pfrag) \
+    accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), accv, 0, 0, 0)
+
+namespace {
+constexpr int SPC = 34;                         // patch columns
+constexpr int STR = 8;                          // tile rows
+constexpr int SNPX = (STR + 2) * SPC;           // 340 patch pixels
+constexpr int SP_INSTR = (SNPX + 7) / 8;        // 43 wave-instructions of 8 pixels x 128 B
+constexpr int SP_BYTES = SP_INSTR * 1024;       // 44032
+constexpr int SROW = SPC * 128;                 // 4352: patch row pitch
+constexpr int SW_BYTES = 72 * 1024;             // 73728: [9 taps][2 chunks][4 channel tiles] fragment blocks
+constexpr int SSMEM = SW_BYTES + 2 * SP_BYTES;  // 161792 of 163840
+constexpr int SCARRY = 8;                       // wave-instructions (64 pixels) of the next patch that come from this one through LDS
+constexpr uint32_t OOB = 0xF0000000u;
+
+// The K loop is 18 sub-steps u = (group g = (chunk kc, horizontal tap dx), vertical tap dy): 8 MFMAs (2 output rows x 4 channel
+// tiles) on 4 kernel fragments and two patch-row fragments.  Fragments of sub-step u+1 are requested before the MFMAs of u:
+// 4 kernel blocks into the other of two register sets, and the ONE patch row u+1 adds (two at the start of a group, into
+// the other patch set).
+template <int U>
+__device__ __forceinline__ void issue_reads(u32x4 (&A)[2][4], u32x4 (&B)[2][4], uint32_t wa, uint32_t wa8, const uint32_t (&pa)[6]) {
+    constexpr int G = U / 3, DY = U % 3, KC = G / 3, DX = G % 3;
+    constexpr int BLK = ((DY * 3 + DX) * 2 + KC) * 4;            // block = (tap * 2 + kc) * 4 + t, tap = dy * 3 + dx
+    if constexpr (DY == 0) { DSR128(B[G & 1][0], pa[G], 0 * SROW); DSR128(B[G & 1][1], pa[G], 1 * SROW); }
+    if constexpr (DY == 1) DSR128(B[G & 1][2], pa[G], 2 * SROW);
+    if constexpr (DY == 2) DSR128(B[G & 1][3], pa[G], 3 * SROW);
+    if constexpr (BLK < 64) {                                     // taps 0..7: 16-bit offsets from wa; tap 8 from wa8 = wa + 64 KB
+        DSR128(A[U & 1][0], wa, (BLK + 0) * 1024); DSR128(A[U & 1][1], wa, (BLK + 1) * 1024);
+        DSR128(A[U & 1][2], wa, (BLK + 2) * 1024); DSR128(A[U & 1][3], wa, (BLK + 3) * 1024);
+    } else {
+        DSR128(A[U & 1][0], wa8, (BLK - 64 + 0) * 1024); DSR128(A[U & 1][1], wa8, (BLK - 64 + 1) * 1024);
+        DSR128(A[U & 1][2], wa8, (BLK - 64 + 2) * 1024); DSR128(A[U & 1][3], wa8, (BLK - 64 + 3) * 1024);
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void k_substeps(u32x4 (&A)[2][4], u32x4 (&B)[2][4], f32x4 (&acc)[2][4], uint32_t wa, uint32_t wa8,
+                                           const uint32_t (&pa)[6]) {
+    constexpr int G = U / 3, DY = U % 3;
+    if constexpr (U + 1 < 18) {
+        issue_reads<U + 1>(A, B, wa, wa8, pa);
+        if constexpr ((U + 1) % 3 == 0) LGKM_WAIT(6); else LGKM_WAIT(5);      // everything but the reads just issued
+    } else {
+        LGKM_WAIT(0);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) MMA16(acc[o][t], A[U & 1][t], B[G & 1][o + DY]);
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (U + 1 < 18) k_substeps<U + 1>(A, B, acc, wa, wa8, pa);
+}
+}  // namespace
+
+// abl (ablation build only): 1 no patch DMA after the first tile, 2 no output stores, 4 no MFMA loop
+__global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a, int nseg, int seglen, int abl) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSMEM];
+    const __bf16* __restrict__ in = (const __bf16*)a.in;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave >> 1, ph = wave & 1;          // row pair, 16-column half of the tile
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + STR - 1) / STR;
+    const int nstrips = a.B * tiles_x, njobs = nstrips * nseg;
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);     // neighbouring strips on one XCD (shared L2)
+    if (wg >= njobs) return;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+
+    // ---- the kernel, once per workgroup, in fragment order.  Block (tap, kc, t), lane l: row r = l & 15 of the MFMA A operand is
+    // output channel n(t, r) = 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3); k group l >> 4 = input channels 32 kc + 8 (l >> 4) ..
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 64 * 9 * 64 * 2, 0x00020000);
+        const uint32_t vw = (uint32_t)((8 * (l15 >> 2) + (l15 & 3)) * 1152 + lq * 16);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int b = wave + 8 * j;
+            const int t = b & 3, kc = (b >> 2) & 1, tap = b >> 3;
+            const int tapsrc = (a.flip & 1) ? 8 - tap : tap;
+            const uint32_t so = (uint32_t)((32 * (t >> 1) + 4 * (t & 1)) * 1152 + tapsrc * 128 + kc * 64);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(smem + b * 1024), 16, vw + so, 0, 0, 0);
+        }
+    }
+
+    // ---- patch DMA: wave-instruction i covers patch pixels 8 i .. 8 i + 7, lane l the 16-byte granule (l & 7) of pixel 8 i + (l >> 3).
+    // This wave issues instructions wave, wave + 8, ...: their patch row / column are fixed per lane, the byte offset of a
+    // strip's column part is computed once per job, a tile only adds its row offset and the row bound.
+    int dma_pr[6], dma_pc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int p = 8 * (wave + 8 * j) + (lane >> 3);
+        dma_pr[j] = p < SNPX ? p / SPC : 1 << 20;              // past the patch: never a valid row
+        dma_pc[j] = p - (p / SPC) * SPC;
+    }
+    int dma_x[6];                                            // ((pr - 1) W + ix) ldi 2 + 16 sg for this job's strip, or INT_MIN
+    auto image_rsrc = [&](int img) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)img * a.H * a.W * a.ldi), (short)0,
+                                                 (int)((((size_t)a.H * a.W - 1) * a.ldi + 64) * 2), 0x00020000);
+    };
+    auto job_columns = [&](int x0, int (&dx_)[6]) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ix = x0 - 1 + dma_pc[j];
+            const int sg = (lane & 7) ^ (dma_pc[j] & 7);
+            dx_[j] = (unsigned)ix < (unsigned)a.W ? (((dma_pr[j] - 1) * a.W + ix) * a.ldi + sg * 8) * 2 : INT32_MIN;
+        }
+    };
+    auto issue_patch = [&](const __amdgpu_buffer_rsrc_t& rs, const int (&dx_)[6], int y0, int first, int buf) {
+        unsigned char* dst = smem + SW_BYTES + buf * SP_BYTES;
+        const int rowoff = y0 * a.W * a.ldi * 2;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int i = wave + 8 * j;
+            if (i < first || i >= SP_INSTR) continue;           // wave-uniform
+            const bool ok = dx_[j] != INT32_MIN && (unsigned)(y0 - 1 + dma_pr[j]) < (unsigned)a.H;
+            const uint32_t off = ok ? (uint32_t)(dx_[j] + rowoff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    auto job_origin = [&](int job, int& img, int& x0, int& ty0, int& ty1) {
+        const int strip = job % nstrips, seg = job / nstrips;
+        img = strip / tiles_x;
+        x0 = (strip - img * tiles_x) * 32;
+        ty0 = seg * seglen;
+        ty1 = ty0 + seglen < tiles_y ? ty0 + seglen : tiles_y;
+    };
+
+    // ---- fragment read addresses
+    const uint32_t wa = lds0 + lane * 16, wa8 = wa + 65536;
+    uint32_t pbase[2][3];                             // + buf * SP_BYTES + r * SROW
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int col = 16 * ph + l15 + dx;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+            pbase[kc][dx] = lds0 + SW_BYTES + (uint32_t)((2 * rp * SPC + col) * 128 + (((kc * 4 + lq) ^ (col & 7)) << 4));
+    }
+
+    // ---- epilogue constants: lane (pixel column l15, quarter lq) holds channels 32 h + 8 lq .. + 8 (h = 0, 1) of its pixel
+    float bias_[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bias_[h][e] = a.bias ? a.bias[32 * h + 8 * lq + e] : 0.f;
+    float cs_s[2][8], cs_q[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs_s[h][e] = 0.f; cs_q[h][e] = 0.f; }
+    __bf16* __restrict__ out = (__bf16*)a.out;
+    const __bf16* __restrict__ addend = (const __bf16*)a.addend;
+
+    // D row 4 lq + j of channel tile t is channel 32 (t >> 1) + 8 lq + 4 (t & 1) + j of pixel column l15: 16 bytes per lane and
+    // (row, half) straight from the accumulators.  Returns the number of store instructions issued (wave-uniform).
+    auto epilogue = [&](const f32x4 (&acc)[2][4], int img, int x0, int y0) -> int {
+        const int x = x0 + 16 * ph + l15;
+        int nst = 0;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int y = y0 + 2 * rp + o;
+            if (!(y < a.H && x0 + 16 * ph < a.W) || UNETRIR_ABL(abl, 2)) continue;   // wave-uniform: lane 0 of an issued store is always live
+            const bool ok = x < a.W;
+            const size_t pix = ((size_t)img * a.H + y) * a.W + x;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[o][2 * h + (e >> 2)][e & 3] + bias_[h][e];
+                if (addend && ok) {
+                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addend + pix * a.ldadd + 32 * h + 8 * lq);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)(__bf16)v[e] + (float)ad[e];
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
+                if (ok) {
+                    if (a.colstat) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float s = (float)ov[e]; cs_s[h][e] += s; cs_q[h][e] += s * s; }
+                    }
+                    *reinterpret_cast<bf16x8*>(out + pix * a.ldo + 32 * h + 8 * lq) = ov;
+                }
+                ++nst;
+            }
+        }
+        return nst;
+    };
+
+    int job = wg, img, x0, ty0, ty1;
+    job_origin(job, img, x0, ty0, ty1);
+    job_columns(x0, dma_x);
+    __amdgpu_buffer_rsrc_t rs_in = image_rsrc(img);
+    issue_patch(rs_in, dma_x, ty0 * STR, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the bias loads are ordinary loads: touch their results here, so that the wait the compiler attaches to their first use
+    // lands in the prologue and not inside the tile loop (where it would drain the patch DMA)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bias_[h][e]));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int cur = 0;
+
+    // Waves w and w + 4 share a SIMD and run the same program: in lockstep both would convert / store / issue DMA at the same
+    // time and leave the matrix pipe idle.  Waves 4-7 therefore DEFER the epilogue of a tile to the start of the next one
+    // (accumulators parked in registers): their epilogue runs beside the K loop of waves 0-3 and vice versa.
+    const bool defer = wave >= 4;
+    f32x4 pacc[2][4];
+    int p_img = 0, p_x0 = 0, p_y0 = 0;
+    bool have_prev = false;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pacc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (;;) {
+        for (int ty = ty0; ty < ty1; ++ty) {
+            const int y0 = ty * STR;
+            // ---- the next tile's patch: from this one (two halo rows through LDS, the rest by DMA) or the first of the next job
+            const bool same = ty + 1 < ty1;
+            const int njob = job + (int)gridDim.x;
+            if (UNETRIR_ABL(abl, 1)) {
+            } else if (same) {
+                // inline asm: an LDS load the compiler can see would make it drain every outstanding store first
+                u32x4 v;
+                const uint32_t src = lds0 + SW_BYTES + cur * SP_BYTES + (STR * SPC) * 128 + tid * 16;
+                const uint32_t dstc = lds0 + SW_BYTES + (cur ^ 1) * SP_BYTES + tid * 16;
+                DSR128(v, src, 0);
+                LGKM_WAIT(0);
+                asm volatile("ds_write_b128 %0, %1" :: "v"(dstc), "v"(v) : "memory");
+                issue_patch(rs_in, dma_x, y0 + STR, SCARRY, cur ^ 1);
+            } else if (njob < njobs) {
+                int img_n, x0_n, ty0_n, ty1_n, dma_n[6];
+                job_origin(njob, img_n, x0_n, ty0_n, ty1_n);
+                job_columns(x0_n, dma_n);
+                const __amdgpu_buffer_rsrc_t rs_n = image_rsrc(img_n);
+                issue_patch(rs_n, dma_n, ty0_n * STR, 0, cur ^ 1);
+            }
+            int nst = 0;                                    // store instructions issued after the DMAs above
+            if (defer && have_prev) nst = epilogue(pacc, p_img, p_x0, p_y0);
+            // ---- K loop: 18 sub-steps, no synchronisation inside
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint32_t pa[6];
+#pragma unroll
+            for (int g = 0; g < 6; ++g) pa[g] = pbase[g / 3][g % 3] + cur * SP_BYTES;
+            u32x4 A[2][4], B[2][4];
+            if (!UNETRIR_ABL(abl, 4)) {
+                issue_reads<0>(A, B, wa, wa8, pa);
+                k_substeps<0>(A, B, acc, wa, wa8, pa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (defer) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pacc[o][t] = acc[o][t];
+                p_img = img; p_x0 = x0; p_y0 = y0; have_prev = true;
+            } else {
+                nst = epilogue(acc, img, x0, y0);
+            }
+            // ---- the next patch is complete once this wave's DMAs are: they are older than the nst output stores, which may
+            //      stay in flight across the barrier
+            if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
+        }
+        job += (int)gridDim.x;
+        if (job >= njobs) break;
+        job_origin(job, img, x0, ty0, ty1);
+        job_columns(x0, dma_x);
+        rs_in = image_rsrc(img);
+    }
+    if (defer && have_prev) epilogue(pacc, p_img, p_x0, p_y0);
+
+    // ---- column statistics: reduce over the 16 pixel columns of a wave, then over the 8 waves; one row per workgroup
+    if (a.colstat) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    cs_s[h][e] += __shfl_xor(cs_s[h][e], off);
+                    cs_q[h][e] += __shfl_xor(cs_q[h][e], off);
+                }
+        float* red = reinterpret_cast<float*>(smem + SW_BYTES);          // [8 waves][64 channels][2]
+        if (l15 == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(wave * 64 + 32 * h + 8 * lq + e) * 2 + 0] = cs_s[h][e];
+                    red[(wave * 64 + 32 * h + 8 * lq + e) * 2 + 1] = cs_q[h][e];
+                }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int ch = tid >> 1, st = tid & 1;
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) t += red[(wv * 64 + ch) * 2 + st];
+            a.colstat[((size_t)blockIdx.x * 64 + ch) * 2 + st] = t;
+        }
+    }
+}
+
+namespace {
+struct SPlan { int grid, nseg, seglen; };
+// jobs = column strips x vertical segments; one persistent workgroup per CU.  Segments only where whole strips would leave
+// CUs idle or unbalanced (fewer strips than CUs, or a strip count that is not a multiple of the CU count).
+inline SPlan splan(const Conv3Args& a) {
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + STR - 1) / STR;
+    const long long nstrips = (long long)a.B * tiles_x;
+    const int cus = 256;
+    int nseg = 1;
+    if (nstrips % cus != 0) {
+        while (nseg < tiles_y && nstrips * nseg < 4LL * cus) ++nseg;       // >= 4 jobs per workgroup: imbalance <= 25 %
+    }
+    SPlan p;
+    p.seglen = (tiles_y + nseg - 1) / nseg;
+    p.nseg = (tiles_y + p.seglen - 1) / p.seglen;
+    const long long jobs = nstrips * p.nseg;
+    p.grid = (int)(jobs < cus ? jobs : cus);
+    return p;
+}
+}  // namespace
+
+bool conv3x3s_applies(const Conv3Args& a) {
+    const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2;
+    return unetrir_cfg().conv3x3s && a.C == 64 && a.N == 64 && !(a.flip & 2) && a.ldi >= 64 && (a.ldi & 7) == 0 && img_bytes < 0x70000000u;
+}
+
+long long conv3x3s_colstat_rows(const Conv3Args& a) { return splan(a).grid; }
+
+int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s) {
+    const SPlan p = splan(a);
+    hipLaunchKernelGGL(conv3x3s_bf16_kernel, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, UNETRIR_ABL_HOST());
+    return (int)hipGetLastError();
+}

@@ -67,8 +67,7 @@ inline ChanPlan chan_plan(long long P, int C, int vec = 4) {
     if (want > maxslab) want = maxslab;
     p.rows_per_slab = (P + want - 1) / want;
     p.nslab = (int)((P + p.rows_per_slab - 1) / p.rows_per_slab);
-    static const int sweep = [] { const char* e = getenv("UNETRIR_CHAN_SWEEP"); return e ? atoi(e) : 1; }();
-    if (sweep) p.rows_per_slab = 0;
+    p.rows_per_slab = 0;          // the slab workgroups sweep the tensor together (interleaved rows), not contiguous slabs
     return p;
 }
 
@@ -592,14 +591,8 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096
     if (b < 1) b = 1;
     return (unsigned)b;
 }
-static inline unsigned chan_pad_lds() {      // A/B: UNETRIR_CHAN_OLDLDS=1 pads the block to the 32 KB it used to take (5 blocks per CU)
-    static const unsigned v = [] { const char* e = getenv("UNETRIR_CHAN_OLDLDS"); return (e && e[0] == '1') ? 24576u : 0u; }();
-    return v;
-}
-static inline int bn_nohoist_flag() {
-    static const int f = [] { const char* e = getenv("UNETRIR_BN_HOIST"); return (e && e[0] == '0') ? 256 : 0; }();
-    return f;
-}
+static inline unsigned chan_pad_lds() { return 0u; }
+static inline int bn_nohoist_flag() { return 0; }
 static inline bool chan_ok(const void* x, int ld, long long P, int C, int vec = 4) {
     return x && P > 0 && C > 0 && C % vec == 0 && ld >= C && ld % vec == 0 && ((uintptr_t)x & 15) == 0;
 }

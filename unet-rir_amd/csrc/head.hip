@@ -156,7 +156,7 @@ int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* 
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
         return UNETRIR_EINVAL;
     if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip) for images up to 256 pixels wide
-        static const bool mfma = [] { const char* e = getenv("UNETRIR_HEAD_MFMA"); return !(e && e[0] == '0'); }();
+        const bool mfma = unetrir_cfg().head_mfma != 0;
         if (mfma && head_mfma_applies(W, C) && (ldx & 7) == 0) return launch_head_fwd_mfma(x, ldx, B, H, W, C, w, bias, y, ldy, s);
     }
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
@@ -173,7 +173,7 @@ int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy
         ws_bytes < (size_t)HEAD_WGRAD_BLOCKS * 2 * HK * HK * C * sizeof(float))
         return UNETRIR_EINVAL;
     if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip)
-        static const bool mfma = [] { const char* e = getenv("UNETRIR_HEAD_MFMA"); return !(e && e[0] == '0'); }();
+        const bool mfma = unetrir_cfg().head_mfma != 0;
         if (mfma && W <= 256 && C % 64 == 0 && (ldx & 7) == 0) {
             int nb = 0;
             const int err = launch_head_wgrad_mfma(x, ldx, B, H, W, C, dy, lddy, (float*)ws, HEAD_WGRAD_BLOCKS, &nb, s);

@@ -539,21 +539,14 @@ int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const 
         if (err != WGRAD3X3R_NOT_TAKEN) return err;
     }
     int ns, per;
-    static const int tall = [] { const char* e = getenv("UNETRIR_WG_TALL"); return e ? atoi(e) : 0; }();
-    const bool big = tall && (stride == 1 ? a.OH % 16 == 0 : a.OH % 8 == 0);
-    wgrad3x3_plan_tph(stride == 1 ? (big ? 16 : TPH_S1) : (big ? 8 : TPH_S2), a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    wgrad3x3_plan_tph(stride == 1 ? TPH_S1 : TPH_S2, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
     const size_t nout = (size_t)a.N * 9 * a.C;
     const bool direct = (ns == 1 && reg == 0.f);
     if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return UNETRIR_EINVAL;
     a.part = direct ? dw : (float*)ws;
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
-    static const int oldpad = [] { const char* e = getenv("UNETRIR_WG_OLDPAD"); return e ? atoi(e) : 0; }();
-    if (oldpad && stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1, 0>), dim3(tiles, ns), dim3(256), 0, s, a);
-    else if (oldpad) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_S2, 0>), dim3(tiles, ns), dim3(256), 0, s, a);
-    else if (big && stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, 16>), dim3(tiles, ns), dim3(256), 0, s, a);
-    else if (big) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, 8>), dim3(tiles, ns), dim3(256), 0, s, a);
-    else if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1>), dim3(tiles, ns), dim3(256), 0, s, a);
+    if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1>), dim3(tiles, ns), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_S2>), dim3(tiles, ns), dim3(256), 0, s, a);
     int err = (int)hipGetLastError();
     if (err || direct) return err;

@@ -7,6 +7,22 @@
 
 #define UNETRIR_MAX_TAPS 36
 
+// Kernel-selection switches (include/unetrir.h: unetrir_config): read once from the environment, replaceable through
+// unetrir_set_config (tests, A/B scripts).  No other environment variable is read by the library.
+const unetrir_config& unetrir_cfg();
+
+// Timing ablations (results invalid: a kernel with a stage switched off) exist only in the separate build that
+// scripts/ use (build.py --ablations -> libunetrir_abl.so, -DUNETRIR_ABLATIONS); in the product library UNETRIR_ABL(...) is
+// a compile-time false and the code behind it is not emitted.
+#ifdef UNETRIR_ABLATIONS
+extern int g_unetrir_abl;                 // set through unetrir_abl_set()
+#define UNETRIR_ABL_HOST() g_unetrir_abl
+#define UNETRIR_ABL(v, bit) (((v) & (bit)) != 0)
+#else
+#define UNETRIR_ABL_HOST() 0
+#define UNETRIR_ABL(v, bit) false
+#endif
+
 // Geometry of one implicit-GEMM launch.  The iteration grid is B x PH x PW "tile pixels" p;
 // the input pixel of tap t is (py*SI + dy_t, px*SI + dx_t) and the output pixel is
 // (py*SO + ooy, px*SO + oox).  tap[t] packs dy (int8) | dx (int8) << 8 | weight-tap index << 16.
@@ -114,6 +130,9 @@ long long conv3x3g_colstat_rows(const Conv3Args& a);
 bool stem3x3_applies(const Conv3Args& a);
 int launch_stem3x3_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3_has_colstat(const Conv3Args& a);
+bool conv3x3s_applies(const Conv3Args& a);          // 64 -> 64 channels: strip kernel with the whole 3x3 kernel resident in LDS
+long long conv3x3s_colstat_rows(const Conv3Args& a);
+int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3h_applies(const Conv3Args& a);
 int launch_conv3x3h_bf16(const Conv3Args& a, hipStream_t s);
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);

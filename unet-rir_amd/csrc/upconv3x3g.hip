@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void upconv3x3g_bf16_kernel(const Conv3Args a)
 }
 
 bool upconv3x3g_applies(const Conv3Args& a) {
-    static const bool on = [] { const char* e = getenv("UNETRIR_UPCONV3X3G"); return !(e && e[0] == '0'); }();
+    const bool on = unetrir_cfg().upconv3x3g != 0;
     const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2, w_bytes = (size_t)a.N * 9 * a.C * 2;
     return on && a.C % 32 == 0 && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
 }

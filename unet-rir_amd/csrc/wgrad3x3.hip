@@ -129,7 +129,7 @@ void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit
     *npx = (OW + TPW - 1) / TPW;
     const long long G = (long long)B * (*npy) * (*npx);
     const long long tiles = (long long)((N + 63) / 64) * ((C + 63) / 64);
-    static const long long target = [] { const char* e = getenv("UNETRIR_WG_TARGET"); return e ? atoll(e) : 512ll; }();
+    const long long target = 512;                        // split-K workgroups aimed for
     long long want = (target + tiles - 1) / tiles;
     long long maxs = (G + 3) / 4;                       // at least 4 patches per slice
     if (maxs < 1) maxs = 1;

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
 }
 
 static void plan_g(int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx) {
-    static const long long target = [] { const char* e = getenv("UNETRIR_WG_TARGET"); return e ? atoll(e) : 512ll; }();
+    const long long target = 512;                        // split-K workgroups aimed for
     *npy = (OH + WTPH - 1) / WTPH;
     *npx = (OW + WTPW - 1) / WTPW;
     const long long G = (long long)B * (*npy) * (*npx);
@@ -245,13 +245,12 @@ static void plan_g(int B, int OH, int OW, int N, int C, int* nsplit, int* per_sp
 
 // stride-1 3x3 weight gradient; WGRAD3X3R_NOT_TAKEN when this kernel does not take the layer (the caller falls back)
 int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
-    static const bool on = [] { const char* e = getenv("UNETRIR_WGRAD3X3G"); return !(e && e[0] == '0'); }();
+    const bool on = unetrir_cfg().wgrad3x3g != 0;
     const size_t x_bytes = (((size_t)a.IH * a.IW - 1) * a.ldx + a.C) * 2, d_bytes = (((size_t)a.OH * a.OW - 1) * a.lddy + a.N) * 2;
     if (!on || a.OH % 8 != 0 || x_bytes >= 0x70000000u || d_bytes >= 0x70000000u || (a.C & 7) || (a.N & 7)) return WGRAD3X3R_NOT_TAKEN;
     int ns, per;
     plan_g(a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
-    static const int nh_env = [] { const char* e = getenv("UNETRIR_WG_NH"); return e ? atoi(e) : 2; }();
-    const int nh = (nh_env == 2 && ns >= 2) ? 2 : 1;
+    const int nh = ns >= 2 ? 2 : 1;                       // two split-K quartets per workgroup share one partial slab
     ns = (ns + nh - 1) / nh;                             // partial slabs = workgroups along the split dimension
     const size_t nout = (size_t)a.N * 9 * a.C;
     const bool direct = (ns == 1 && reg == 0.f);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3r_bf16_kernel(const Wgrad3Args
 
 // split-K plan for TPH x 16 patches: about `target` workgroups, at least 4 patches per slice
 static void plan_r(int TPH, int B, int OH, int OW, int N, int C, int* nsplit, int* per_split, int* npy, int* npx) {
-    static const long long target = [] { const char* e = getenv("UNETRIR_WG_TARGET"); return e ? atoll(e) : 512ll; }();
+    const long long target = 512;                        // split-K workgroups aimed for
     *npy = (OH + TPH - 1) / TPH;
     *npx = (OW + RW_TPW - 1) / RW_TPW;
     const long long G = (long long)B * (*npy) * (*npx);
@@ -169,7 +169,7 @@ static void plan_r(int TPH, int B, int OH, int OW, int N, int C, int* nsplit, in
 
 // stride-1 3x3 weight gradient; returns WGRAD3X3R_NOT_TAKEN when this kernel does not take the layer (the caller falls back)
 int launch_wgrad3x3r_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
-    static const bool on = [] { const char* e = getenv("UNETRIR_WGRAD3X3R"); return !(e && e[0] == '0'); }();
+    const bool on = unetrir_cfg().wgrad3x3r != 0;
     if (!on || a.OH % 8 != 0) return WGRAD3X3R_NOT_TAKEN;
     int ns, per;
     plan_r(8, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);

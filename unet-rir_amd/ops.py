@@ -427,6 +427,28 @@ def adam(theta, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0)
                                       float(grad_scale), _stream()), "adam")
 
 
+# ---- kernel-selection switches --------------------------------------------------------------------
+
+def get_config():
+    """The kernel-selection switches in effect (unetrir_config) as a dict."""
+    c = _lib.Config()
+    check(_lib.lib().unetrir_get_config(C.byref(c)), "get_config")
+    return {n: getattr(c, n) for n, _ in _lib.Config._fields_}
+
+
+def set_config(**switches):
+    """Replace kernel-selection switches (tests, A/B scripts), e.g. set_config(conv3x3s=0); returns the previous values."""
+    old = get_config()
+    new = dict(old)
+    for k, v in switches.items():
+        if k not in new:
+            raise KeyError(f"unknown switch {k}")
+        new[k] = int(v)
+    c = _lib.Config(*[new[n] for n, _ in _lib.Config._fields_])
+    check(_lib.lib().unetrir_set_config(C.byref(c)), "set_config")
+    return old
+
+
 # ---- profiling hooks -------------------------------------------------------------------------
 
 def prof_enable(on):
