@@ -98,8 +98,14 @@ def l2_regularized(cfg: ResAEConfig):
 
 
 def init_params(cfg: ResAEConfig, seed_name="rp", randomize_all=False, dtype=np.float32):
+    return init_from_shapes(param_shapes(cfg), seed_name, randomize_all, dtype)
+
+
+def init_from_shapes(shapes, seed_name, randomize_all=False, dtype=np.float32):
+    """Keras default initialisers for a name -> Keras-shape table (glorot_uniform kernels, zero biases, gamma 1, beta 0,
+    Embedding U(-0.05, 0.05)); `randomize_all` perturbs biases / gamma / beta so parity tests exercise them."""
     out = {}
-    for name, shp in param_shapes(cfg).items():
+    for name, shp in shapes.items():
         key = f"{seed_name}/{name}"
         if name == "embedding":
             a = detrand.uniform(key, shp, -0.05, 0.05)

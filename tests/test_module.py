@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from oracle import torch_ref as R, torch_resae as RA  # noqa: E402
+from oracle import torch_ae as AE, torch_ref as R, torch_resae as RA  # noqa: E402
 
 H = W = 16
 F0 = 8
@@ -218,6 +218,42 @@ def test_resae_boundary_class(env):
     full = model.predict_stft([nhwc(spec_in), env.t(emb)])
     env.sync()
     assert float((rec - full).abs().max()) <= 1e-6
+
+
+def test_autoencoder_boundary_class(env, tmp_path):
+    """Autoencoder(input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons, name)
+    (dl_models/autoencoder.py:41-46; main_training.py:118-129): .model, .encoder / .decoder, Trainer, save / load."""
+    B = 2
+    cfg = AE.AEConfig(H, W, (8, 8, 16, 16), (3, 3, 3, 3), (2, 2, 2, 2), 8, 16)
+    params = AE.init_params(cfg, randomize_all=True, dtype=np.float64)
+    spec_in, emb, spec_out = R.synthetic_batch(R.Config(H, W), B)
+    model = env.U.Autoencoder((H, W, 2), (2, 16), cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim,
+                              cfg.n_neurons, name="ae", batch_size=B, device=env.device, runtime=env.rt, dropout=False)
+    model.engine.load_keras_params(params)
+    tr = env.U.Trainer(model, lr=1e-3, dropout=False)
+    got_loss = tr.step(env.t(spec_in), env.t(emb), env.t(spec_out), return_loss=True)
+    env.sync()
+    want_loss, _, want_pred, grads = AE.loss_and_grads(params, spec_in, emb, spec_out, cfg, 0.9, B, 1)
+    assert abs(got_loss - want_loss) <= 1e-5 * abs(want_loss)
+    assert float((model.engine.pred.double().cpu() - want_pred).abs().max()) <= 1e-4
+    got = model.engine.export_keras_grads()
+    assert set(got) == set(grads)
+    floor = 1e-6 * max(float(g.abs().max()) for g in grads.values())
+    for n, g in grads.items():
+        e = float((got[n].double() - g).abs().max())
+        assert e <= 1e-3 * float(g.abs().max()) + floor, (n, e)
+    nhwc = lambda a: env.t(a).permute(0, 2, 3, 1).contiguous()
+    z = model.encoder([nhwc(spec_in), env.t(emb)])
+    assert tuple(z.shape) == (B, cfg.latent_space_dim)
+    rec = model.decoder(z).clone()
+    full = model.predict_stft([nhwc(spec_in), env.t(emb)])
+    env.sync()
+    assert float((rec - full).abs().max()) <= 1e-6
+    model.save(str(tmp_path))
+    again = env.U.Autoencoder.load(str(tmp_path), batch_size=B, device=env.device, runtime=env.rt)
+    assert torch.equal(again.predict_stft([nhwc(spec_in), env.t(emb)]), full)
+    # main_training.py:118-129 configuration at the reference's 144 x 160: parameter count of the Keras model
+    assert sum(int(np.prod(s)) for s in AE.param_shapes(AE.AEConfig(144, 160)).values()) == 28_830_658
 
 
 def test_save_load_round_trip(env, tmp_path):

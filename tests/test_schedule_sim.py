@@ -25,12 +25,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 H = W = 16
 F0 = 4
-KINDS = ("unet", "graph3", "resae")     # UNetEngine (mode 0, hand schedule), UNetGraphEngine mode 3, ResAEEngine
+KINDS = ("unet", "graph3", "resae", "ae")     # UNetEngine (mode 0, hand schedule), UNetGraphEngine mode 3, ResAEEngine, AutoencoderEngine
 
 
 def _oracle(kind):
     """(cfg, initial parameters, loss_and_grads(params, spec_in, emb, spec_out, global_batch, n_replicas)) of one model kind."""
-    from oracle import torch_ref as R, torch_resae as RA
+    from oracle import torch_ref as R, torch_resae as RA, torch_ae as AE
+    if kind == "ae":
+        cfg = AE.AEConfig(H, W, (4, 8, 8, 8), (3, 3, 3, 3), (2, 2, 2, 2), 8, 16)
+        lg = lambda p, a, e, b, gb, nr: AE.loss_and_grads(p, a, e, b, cfg, 0.9, gb, nr, None, None)
+        return cfg, AE.init_params(cfg, randomize_all=True, dtype=np.float64), lg
     if kind == "resae":
         cfg = RA.ResAEConfig(H, W, (4, 8, 8, 8), (3, 3, 3, 3), (2, 2, 2, 2), 8, 16)
         lg = lambda p, a, e, b, gb, nr: RA.loss_and_grads(p, a, e, b, cfg, 0.9, gb, nr, None, None)
@@ -73,6 +77,9 @@ def _build(rt, B, overlap, world=1, bucket_bytes=32 << 20, kind="unet", **kw):
         eng = U.UNetEngine(H, W, B, F0=F0, k=3, device="cpu", runtime=rt, overlap_wgrad=overlap, n_replicas=world, **kw)
     elif kind == "graph3":
         eng = U.UNetGraphEngine(H, W, B, F0=F0, k=3, mode=3, device="cpu", runtime=rt, n_replicas=world)
+    elif kind == "ae":
+        eng = U.AutoencoderEngine(H, W, B, cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim, cfg.n_neurons,
+                                  device="cpu", runtime=rt, n_replicas=world)
     else:
         eng = U.ResAEEngine(H, W, B, cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim, cfg.n_neurons,
                             device="cpu", runtime=rt, n_replicas=world)
@@ -95,7 +102,7 @@ def _check_params(eng, want):
         assert err <= P_ATOL, (n, err)
 
 
-@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae")])
+@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae"), (False, "ae")])
 def test_full_step_on_the_product_schedule_matches_oracle(monkeypatch, overlap, kind):
     import cpu_ops
     from sim_runtime import SimRuntime
@@ -110,9 +117,10 @@ def test_full_step_on_the_product_schedule_matches_oracle(monkeypatch, overlap, 
     loss = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
     assert abs(loss - want_l[0]) <= 1e-5 * abs(want_l[0])
     got_g = eng.export_keras_grads()
+    floor = 1e-6 * max(float(g.abs().max()) for g in want_g.values())     # tensors whose exact gradient is ~0 (behind a 2-sample BatchNorm)
     for n, g in want_g.items():
         e = float((got_g[n].double() - g).abs().max())
-        assert e <= 1e-4 * float(g.abs().max()) + 1e-9, (n, e)
+        assert e <= 1e-4 * float(g.abs().max()) + floor, (n, e)
     loss2 = tr.step(t(spec_in), t(emb), t(spec_out), return_loss=True)
     assert abs(loss2 - want_l[1]) <= 1e-5 * abs(want_l[1])
     _check_params(eng, want_p)
@@ -187,7 +195,7 @@ def _dp_worker(rank, world, port, out_path, overlap, kind):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae")])
+@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae"), (False, "ae")])
 def test_two_rank_trainer_step_equals_single_process_oracle(tmp_path, overlap, kind):
     world = 2
     out = str(tmp_path / "dp")

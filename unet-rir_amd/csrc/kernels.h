@@ -91,6 +91,7 @@ struct Wgrad3ArgsH {
     int pad_t, pad_l;
     float* part;                              // fp32 partial slabs [nsplit][N][9][C]
     int patches_per_split, npy, npx;
+    int xcd_remap;                            // wgrad3x3g: workgroups that share x / dy patches (one split, all tiles) on one XCD
 };
 int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
 int launch_igemm_fwd_bf16_x4(const IgemmArgsH* a, hipStream_t s);

@@ -54,14 +54,25 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
     const int h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
 
+    // (tile, split) of this workgroup.  Dispatch deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2),
+    // which would put the tiles of one split - the workgroups that read the SAME x and dy patches at the same time - on
+    // different XCDs: every patch then comes from HBM once per sharer (2.2x the algorithmic bytes at 128 -> 128).  Remapped:
+    // XCD x runs splits x ns/8 .. (x+1) ns/8, all tiles of a split next to each other.
+    int tile_id = blockIdx.x, split_id = blockIdx.y;
+    if (a.xcd_remap) {
+        const int tiles = gridDim.x, per_xcd = gridDim.y >> 3;
+        const int id = blockIdx.y * tiles + blockIdx.x, k = id >> 3;
+        split_id = (id & 7) * per_xcd + k / tiles;
+        tile_id = k - (k / tiles) * tiles;
+    }
     const int ntC = (a.C + 63) / 64;
-    const int rt = blockIdx.x / ntC, ct = blockIdx.x - rt * ntC;
+    const int rt = tile_id / ntC, ct = tile_id - rt * ntC;
     const int n0 = rt * 64, c0 = ct * 64;
     const int per_img = a.npy * a.npx;
     const int G = a.B * per_img;
     // the workgroup's slice is NH * patches_per_split patches; quartet `half` takes the half-th part.  Every quartet runs
     // n_it iterations (the first quartet's count); patches past the end are all-zero DMAs and add nothing.
-    const int G0 = blockIdx.y * NH * a.patches_per_split;
+    const int G0 = split_id * NH * a.patches_per_split;
     const int g0 = G0 + half * a.patches_per_split;
     const int n_it = min(a.patches_per_split, G - G0);
 
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         __syncthreads();
         if (half == 1) return;
     }
-    float* part = a.part + (size_t)blockIdx.y * a.N * 9 * a.C;
+    float* part = a.part + (size_t)split_id * a.N * 9 * a.C;
     const int c = c0 + wc * 32 + (lane & 31);
     if (c < a.C) {
 #pragma unroll
@@ -258,6 +269,7 @@ int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, v
     a.part = direct ? dw : (float*)ws;
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
+    a.xcd_remap = (tiles > 1 && ns % 8 == 0 && !UNETRIR_ABL(UNETRIR_ABL_HOST(), 512)) ? 1 : 0;
     if (nh == 2) hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<2>, dim3(tiles, ns), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<1>, dim3(tiles, ns), dim3(256), 0, s, a);
     const int err = (int)hipGetLastError();

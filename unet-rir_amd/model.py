@@ -4,6 +4,7 @@ whose forward and backward run on the HIP engines.
   ``UNet``   dl_models/u_net.py:34-64  - constructor names / order / defaults of the reference, every ``mode`` (0: the
              hand-scheduled ``UNetEngine``, fp32 or bf16 storage, optional side-stream schedule; 1-3: ``UNetGraphEngine``)
   ``ResAE``  dl_models/res_ae.py:35-70 - the residual autoencoder, with ``.encoder`` / ``.decoder`` / ``.model``
+  ``Autoencoder``  dl_models/autoencoder.py:34-62 - the plain conv / conv-transpose autoencoder, same surface
 
 Both keep the reference's call shape ``model.model([spec_in, emb], training=...)`` (NHWC, main_training.py:261),
 ``model.model.trainable_variables`` / ``.losses``, ``summary()``, ``save()`` / ``load()`` / ``load_weights()``,
@@ -34,6 +35,7 @@ from torch import nn
 
 from . import ops
 from .device import HipRuntime
+from .ae import AutoencoderEngine
 from .engine import L2_COEF, UNetEngine
 from .resae import ResAEEngine
 from .unet_graph import UNetGraphEngine
@@ -323,13 +325,13 @@ class _SubModel:
     predict = __call__
 
 
-class ResAE(_EngineModule):
-    """Residual autoencoder of the reference (dl_models/res_ae.py:35-70; main_training.py:130-140 builds it with filters
-    (32,64,128,256), kernels 3, strides 2, latent 32, n_neurons 1024 - BASELINE.json configs[4]).  Constructor arguments keep
-    the reference's names and order; ``batch_size``, ``device``, ``n_replicas``, ``dropout``, ``fold_l2`` are additions."""
+class _AEFamily(_EngineModule):
+    """Constructor surface shared by the reference's autoencoder classes (dl_models/res_ae.py:41-50, dl_models/autoencoder.py:41-46):
+    (input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons, name)."""
+    ENGINE = None
 
     def __init__(self, input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
-                 name="ResAE", batch_size=None, device="cuda:0", n_replicas=1, dropout=True, fold_l2=True, runtime=None):
+                 name, batch_size=None, device="cuda:0", n_replicas=1, dropout=True, fold_l2=True, runtime=None):
         super().__init__(device, batch_size, n_replicas, dropout, fold_l2, runtime)
         shp = tuple(input_shape)
         if len(shp) != 3 or 2 not in (shp[0], shp[2]):
@@ -344,7 +346,7 @@ class ResAE(_EngineModule):
         self._shape_before_bottleneck = self.engine.shape_before_bottleneck
 
     def _new_engine(self, B, share):
-        return ResAEEngine(self.H, self.W, B, self.conv_filters, self.conv_kernels, self.conv_strides, self.latent_space_dim,
+        return self.ENGINE(self.H, self.W, B, self.conv_filters, self.conv_kernels, self.conv_strides, self.latent_space_dim,
                            self.n_neurons, self.inf_vector_shape, device=self._device, n_replicas=self.n_replicas,
                            runtime=self._rt, share=share)
 
@@ -356,7 +358,7 @@ class ResAE(_EngineModule):
     def decoder(self):
         return _SubModel(self, "decoder")
 
-    def _ctor_parameters(self):            # dl_models/res_ae.py:193-201
+    def _ctor_parameters(self):            # dl_models/res_ae.py:193-201, dl_models/autoencoder.py:177-186
         return [self.input_shape, self.inf_vector_shape, self.conv_filters, self.conv_kernels, self.conv_strides,
                 self.latent_space_dim, self.n_neurons]
 
@@ -367,3 +369,27 @@ class ResAE(_EngineModule):
         ae = cls(*prm, batch_size=batch_size, device=device, **kw)
         ae.load_weights(os.path.join(save_folder, "weights.npz"))
         return ae
+
+
+class Autoencoder(_AEFamily):
+    """Convolutional autoencoder of the reference (dl_models/autoencoder.py:34-62; main_training.py:118-129 builds it with
+    filters (64,128,256,512), kernels 3, strides 2, latent 64, n_neurons 2048).  Constructor arguments keep the reference's
+    names and order; ``batch_size``, ``device``, ``n_replicas``, ``dropout``, ``fold_l2`` are additions."""
+    ENGINE = AutoencoderEngine
+
+    def __init__(self, input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
+                 name="Autoencoder", **kw):
+        super().__init__(input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
+                         name, **kw)
+
+
+class ResAE(_AEFamily):
+    """Residual autoencoder of the reference (dl_models/res_ae.py:35-70; main_training.py:130-140 builds it with filters
+    (32,64,128,256), kernels 3, strides 2, latent 32, n_neurons 1024 - BASELINE.json configs[4]).  Constructor arguments keep
+    the reference's names and order; ``batch_size``, ``device``, ``n_replicas``, ``dropout``, ``fold_l2`` are additions."""
+    ENGINE = ResAEEngine
+
+    def __init__(self, input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
+                 name="ResAE", **kw):
+        super().__init__(input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
+                         name, **kw)
