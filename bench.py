@@ -201,18 +201,19 @@ class Runner:
         torch.cuda.empty_cache()
         return res
 
-    def resae_run(self, steps, warmup):
+    def resae_run(self, steps, warmup, dtype="bf16"):
         """BASELINE.json configs[4]: ResAE (main_training.py:130-140: filters 32..256, k 3, s 2, latent 32, n_neurons 1024),
         batch 32 of [2,256,256], through its boundary class and the Trainer."""
         U = self.U
         model = U.ResAE((256, 256, 2), (2, 16), (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 16 * 64, name="resae",
-                        batch_size=32, device=self.device)
+                        batch_size=32, device=self.device, dtype=dtype)
         tr = U.Trainer(model, lr=5e-7, alpha=0.9)
         spec_in, emb, spec_out = synthetic_batch(32, 256, 256, self.device, 1234)
         dt, _ = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, 0)
         res = {"workload": "BASELINE.json configs[4]: ResAE filters (32,64,128,256), k 3, s 2, latent 32, n_neurons 1024, batch 32 of "
-                           "[2,256,256], full train step, fp32 storage", "value": 32 * steps / dt, "unit": "spectrograms/s",
-               "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "params": model.engine.n_params(), "dtype": "f32"}
+                           "[2,256,256], full train step, " + ("bf16 storage of the convolutional trunk" if dtype == "bf16" else "fp32 storage"),
+               "value": 32 * steps / dt, "unit": "spectrograms/s",
+               "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "params": model.engine.n_params(), "dtype": dtype}
         del tr, model
         torch.cuda.empty_cache()
         return res
@@ -348,7 +349,8 @@ def main():
                 "workload": "BASELINE.json configs[3]'s model on ONE GPU: UNet 5 down/5 up, number_filters_0=128, kernels=3, batch 16 of "
                             "[2,512,512], full train step, bf16 storage", "value": c4["value"], "unit": "spectrograms/s",
                 "ms_per_step": c4["ms_per_step"], "steps": c4["steps"], "warmup": c4["warmup"], "params": c4["params"], "dtype": "bf16"}
-            configs["cfg5_resae"] = run.resae_run(5, 2)
+            configs["cfg5_resae"] = run.resae_run(5, 2, "bf16")
+            configs["cfg5_resae_fp32"] = run.resae_run(5, 2, "f32")
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()

@@ -229,7 +229,7 @@ int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long
  *      copies are bfloat16 (unetrir_bf16), accumulation is fp32 (v_mfma_f32_32x32x16_bf16), bias / BatchNorm parameters /
  *      statistics / weight gradients / master weights stay fp32.  Channel counts and pixel strides are multiples of 8
  *      (16-byte rows).  Same call sites as the _f32 entry points above.  The weight gradient exists for 3x3 kernels
- *      (the 1x1 conv and the Dense layer of the information-vector branch stay fp32). */
+ *      and 1x1 kernels (the Dense layers stay fp32). */
 int unetrir_conv2d_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
                             const float* bias, const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy,
                             unetrir_stream_t stream);
@@ -318,6 +318,13 @@ int unetrir_sigmoid_bwd_bf16(const float* pred, const float* dpred, int B, int H
 int unetrir_add_f32_to_bf16(const unetrir_bf16* a, const float* b, unetrir_bf16* y, long long n,
                             unetrir_stream_t stream);
 int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetrir_stream_t stream);
+int unetrir_cast_f32_to_bf16(const float* a, unetrir_bf16* y, long long n, unetrir_stream_t stream);
+/* residual-block glue in bf16 storage (as unetrir_bn_act_add_f32 / unetrir_act_bwd_f32; C % 8 == 0): the graphs of
+ * dl_models/res_ae.py and the feature-block modes 1-3 of dl_models/u_net.py on the bf16 convolution kernels */
+int unetrir_bn_act_add_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* affine, int act,
+                            const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy, unetrir_stream_t stream);
+int unetrir_act_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* out, int ldo, long long P, int C, int act,
+                         unetrir_bf16* g, int ldg, unetrir_stream_t stream);
 
 /* ---- waveform <-> feature transforms at the two ends of the data path; all fp32 in HBM,
  *      fp64 direct DFT inside.  n_fft is a power of two <= 1024, win_length <= n_fft, window = periodic Hann centred in

@@ -260,6 +260,31 @@ class CpuOps:
         dlogits.base.zero_()
         dlogits.base[..., :2] = (dpred.to(D) * p * (1 - p)).permute(0, 2, 3, 1).to(dlogits.base.dtype)
 
+    # ---- bf16 glue
+    def make_cast_table(self, entries, device):
+        return list(entries), len(entries)
+
+    def cast_weights_batched(self, table):
+        ents, _ = table
+        for (w, same, tr, N, T, C_, Cp, Np) in ents:
+            self.rt.touch([w], [same, tr], "cast_weights")
+            if same is not None:
+                same.reshape(N, T, Cp)[..., :C_] = w.reshape(N, T, C_).to(same.dtype)
+            if tr is not None:
+                tr.reshape(C_, T, Np)[..., :N] = w.reshape(N, T, C_).permute(2, 1, 0).to(tr.dtype)
+
+    def add_f32_to_bf16(self, a, b, y):
+        self.rt.touch([a, b], [y], "add_f32_to_bf16")
+        y.base.copy_((a.base.to(D) + b.base.to(D)).to(y.base.dtype))
+
+    def cast_bf16_to_f32(self, a, y):
+        self.rt.touch([a], [y], "cast_bf16_to_f32")
+        y.base.copy_(a.base.to(y.base.dtype))
+
+    def cast_f32_to_bf16(self, a, y):
+        self.rt.touch([a], [y], "cast_f32_to_bf16")
+        y.base.copy_(a.base.to(y.base.dtype))
+
     # ---- information vector
     def index_to_i32(self, idx, out):
         self.rt.touch([idx], [out], "index_to_i32")

@@ -147,6 +147,11 @@ _SIGS = {
     "unetrir_sigmoid_bwd_bf16": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
     "unetrir_add_f32_to_bf16": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_longlong, c_stream]),
     "unetrir_cast_bf16_to_f32": (C.c_int, [c_f32p, c_f32p, C.c_longlong, c_stream]),
+    "unetrir_cast_f32_to_bf16": (C.c_int, [c_f32p, c_f32p, C.c_longlong, c_stream]),
+    "unetrir_bn_act_add_bf16": (C.c_int, [c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
+                                          C.c_int, c_stream]),
+    "unetrir_act_bwd_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, C.c_int, c_f32p, C.c_int,
+                                       c_stream]),
     "unetrir_bn_inference_affine_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, c_f32p, c_stream]),
     "unetrir_dropout_mask_f32": (C.c_int, [c_f32p, C.c_longlong, C.c_float, C.c_ulonglong, C.c_ulonglong, c_stream]),
     "unetrir_index_to_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, c_stream]),

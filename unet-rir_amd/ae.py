@@ -15,8 +15,8 @@ class AutoencoderEngine(GraphEngine):
 
     def __init__(self, H, W, B, conv_filters=(64, 128, 256, 512), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
                  latent_space_dim=64, n_neurons=2048, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None,
-                 share=None):
-        super().__init__(B, device, n_replicas, runtime, share)
+                 share=None, dtype="f32"):
+        super().__init__(B, device, n_replicas, runtime, share, dtype)
         self.H, self.W = H, W
         self.filters, self.kernels, self.strides = tuple(conv_filters), tuple(conv_kernels), tuple(conv_strides)
         if any(f % 4 for f in self.filters) or any(s not in (1, 2) for s in self.strides):
@@ -34,11 +34,11 @@ class AutoencoderEngine(GraphEngine):
         """dl_models/autoencoder.py:210-417."""
         B, dev = self.B, self.device
         n = len(self.filters)
-        self.x4 = self._reg(Node(ops.new_act(B, self.H, self.W, 4, dev), needs_grad=False))
+        self.x4 = self._reg(Node(ops.new_act(B, self.H, self.W, self.PAD, dev, dtype=self.adt), needs_grad=False))
         x = self.x4
         for i in range(n):        # encoder: Conv2D(l2) -> BatchNormalization -> ReLU (:384-402)
             c = self._conv(x, f"encoder_conv_layer_{i + 1}", self.filters[i], self.kernels[i], self.strides[i], False,
-                           pad_in=4 if i == 0 else 0)
+                           pad_in=self.PAD if i == 0 else 0)
             x = self._bn_act(c, f"encoder_bn_{i + 1}", RELU)
         h, w, c = x.a.H, x.a.W, x.a.C
         self.shape_before_bottleneck = (h, w, c)
@@ -47,7 +47,7 @@ class AutoencoderEngine(GraphEngine):
         vec = self._dense(flat_vec, "encoder_inf_dense", self.n_neurons)
         vecd = self._dropout(vec, "inf")
         # concatenate([Flatten(x), y]) -> Dense(latent) (:404-417); the concat is a copy of two row blocks
-        cat = self._new(1, 1, n_feat + self.n_neurons)
+        cat = self._new(1, 1, n_feat + self.n_neurons, f32=True)     # fp32 (the copies below convert the trunk half)
         x_last = x
 
         def cat_fwd():
@@ -63,6 +63,8 @@ class AutoencoderEngine(GraphEngine):
         d = self._dense(z, "decoder_dense", n_feat)               # decoder: Dense -> Dropout -> Reshape (:245-265)
         dd = self._dropout(d, "dec")
         x = self._reshape(dd, h, w, c)
+        if self.dtype == "bf16":
+            x = self._cast(x)                                  # the Dense branch is fp32, the transposed-conv trunk bf16
         ct = self._conv(x, "decoder_conv_transpose_layer_0", self.filters[-1], self.kernels[-1], 1, True)      # stride 1 (:267-285)
         x = self._bn_act(ct, "decoder_bn_0", RELU)
         for layer_index in reversed(range(1, n)):                 # _add_conv_transpose_layers (:287-320)
@@ -71,7 +73,7 @@ class AutoencoderEngine(GraphEngine):
                             self.strides[layer_index - 1], True)
             x = self._bn_act(ct, f"decoder_bn_{num}", RELU)
         # _add_decoder_output (:322-335): Conv2DTranspose(2, k0, s0, 'same') + sigmoid; Cout padded 2 -> 4, no l2
-        self.logits = self._conv(x, f"decoder_out_{n}", 2, self.kernels[0], self.strides[0], True, followed_by_bn=False, pad_out=4,
+        self.logits = self._conv(x, f"decoder_out_{n}", 2, self.kernels[0], self.strides[0], True, followed_by_bn=False, pad_out=self.PAD,
                                  l2=False)
         if (self.logits.a.H, self.logits.a.W) != (self.H, self.W):
             raise ValueError("decoder output size does not match the input size")

@@ -236,7 +236,13 @@ size_t wgrad_ws_bytes(const unetrir_conv_geom* g) {
     wgrad_args(g, g->Cin, g->Cout, &a);
     int ns; long long per;
     wgrad_plan(a.g, &ns, &per);
-    return (size_t)ns * g->Cout * g->k * g->k * g->Cin * sizeof(float);
+    size_t bytes = (size_t)ns * g->Cout * g->k * g->k * g->Cin * sizeof(float);
+    if (g->k == 1) {          // the bf16 1x1 kernel has its own split plan: the workspace serves both storage modes
+        const Same sy = same_geom(g->H, 1, g->stride), sx = same_geom(g->W, 1, g->stride);
+        const size_t b16 = wgrad1x1_bf16_ws_bytes(g->B, sy.out, sx.out, g->Cout, g->Cin);
+        if (b16 > bytes) bytes = b16;
+    }
+    return bytes;
 }
 
 int conv_wgrad_impl(const unetrir_conv_geom* g, const float* x, int ldx, const float* dy, int lddy, float* dw,
@@ -258,13 +264,14 @@ int conv_wgrad_impl(const unetrir_conv_geom* g, const float* x, int ldx, const f
 
 int conv_wgrad_bf16_impl(const unetrir_conv_geom* g, const __bf16* x, int ldx, const __bf16* dy, int lddy, float* dw, float reg,
                          const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (g->k != 3) return UNETRIR_EINVAL;       // bf16 weight gradients exist for the 3x3 layers (the others stay fp32)
-    const Same sy = same_geom(g->H, 3, g->stride), sx = same_geom(g->W, 3, g->stride);
+    if (g->k != 3 && g->k != 1) return UNETRIR_EINVAL;       // bf16 weight gradients exist for 3x3 and 1x1 kernels
+    const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     Wgrad3ArgsH a3{};
     a3.x = x; a3.ldx = ldx; a3.IH = g->H; a3.IW = g->W;
     a3.dy = dy; a3.lddy = lddy; a3.OH = sy.out; a3.OW = sx.out;
     a3.B = g->B; a3.C = g->Cin; a3.N = g->Cout;
     a3.pad_t = sy.before; a3.pad_l = sx.before;
+    if (g->k == 1) return launch_wgrad1x1_bf16(a3, g->stride, dw, reg, w, ws, ws_bytes, s);
     return launch_wgrad3x3_bf16(a3, g->stride, dw, reg, w, ws, ws_bytes, s);
 }
 
@@ -410,7 +417,7 @@ int unetrir_conv2d_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x,
 
 int unetrir_conv2d_transpose_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* wt,
                                       const float* bias, unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
-    if (!geom_ok(g) || g->stride != 2 || !x || !wt || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout)
+    if (!geom_ok(g) || !x || !wt || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout)
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
@@ -420,7 +427,7 @@ int unetrir_conv2d_transpose_fwd_bf16(const unetrir_conv_geom* g, const unetrir_
 int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* w,
                                         const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx,
                                         unetrir_stream_t stream) {
-    if (!geom_ok(g) || g->stride != 2 || !dy || !w || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin)
+    if (!geom_ok(g) || !dy || !w || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin)
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(&c), (hipStream_t)stream);
@@ -431,7 +438,7 @@ int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetri
 int unetrir_conv2d_transpose_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy,
                                         int lddy, float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
                                         unetrir_stream_t stream) {
-    if (!geom_ok(g) || g->stride != 2 || !x || !dy || !dw || (g->Cin & 7) || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) ||
+    if (!geom_ok(g) || !x || !dy || !dw || (g->Cin & 7) || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) ||
         !ldh_ok(ldx, g->Cin) || (reg_coef != 0.f && !w))
         return UNETRIR_EINVAL;
     const unetrir_conv_geom c = adjoint_geom(g);

@@ -838,7 +838,37 @@ __global__ void cast_bf16_to_f32_kernel(const __bf16* __restrict__ a, float* __r
         st4(y + i * 4, ld4(a + i * 4));
 }
 
+__global__ void cast_f32_to_bf16_kernel(const float* __restrict__ a, __bf16* __restrict__ y, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        st4(y + i * 4, ld4(a + i * 4));
+}
+
 extern "C" {
+
+/* bf16-storage forms of the residual-block glue (unetrir_bn_act_add_f32 / unetrir_act_bwd_f32): C % 8 == 0, 16-byte rows */
+int unetrir_bn_act_add_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* affine, int act, const unetrir_bf16* addend,
+                            int ldadd, unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
+    if (!chan_ok(x, ldx, P, C, 8) || !y || ldy < C || (ldy & 7) || act < 0 || act > 2 || (addend && (ldadd < C || (ldadd & 7))))
+        return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_apply_kernel<__bf16>, dim3(grid_for(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, ldx, P, C,
+                       affine, act, (__bf16*)y, ldy, (const __bf16*)addend, ldadd);
+    return (int)hipGetLastError();
+}
+
+int unetrir_act_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* out, int ldo, long long P, int C, int act,
+                         unetrir_bf16* g, int ldg, unetrir_stream_t stream) {
+    if (!chan_ok(out, ldo, P, C, 8) || !chan_ok(da, ldda, P, C, 8) || !g || ldg < C || (ldg & 7) || act < 1 || act > 2) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(grid_for(P * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const __bf16*)da, ldda,
+                       (const __bf16*)out, ldo, P, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, act,
+                       (__bf16*)g, ldg);
+    return (int)hipGetLastError();
+}
+
+int unetrir_cast_f32_to_bf16(const float* a, unetrir_bf16* y, long long n, unetrir_stream_t stream) {
+    if (!a || !y || n <= 0 || (n & 3)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, (__bf16*)y, n / 4);
+    return (int)hipGetLastError();
+}
 
 int unetrir_bn_stats_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps,
                           float momentum, float* moving_mean, float* moving_var, float* affine, float* saved, void* ws,

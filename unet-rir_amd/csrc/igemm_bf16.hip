@@ -241,9 +241,12 @@ __global__ __launch_bounds__(256) void igemm_fwd_bf16_kernel4(const IgemmArgsH4 
 // ------------------------------------------------------------------------------------------------
 #define TPW 8
 
-template <int SI, int TPH, int PADV = 1>
+// KS = 3: the 3x3 layers.  KS = 1: the 1x1 layers of the residual graphs (dl_models/res_ae.py:455-512) - the same patch scheme
+// with one tap and no halo (pad_t = pad_l = 0).
+template <int SI, int TPH, int PADV = 1, int KS = 3>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH a) {
-    constexpr int XH = (TPH - 1) * SI + 3, XW = (TPW - 1) * SI + 3;
+    constexpr int NT = KS * KS;
+    constexpr int XH = (TPH - 1) * SI + KS, XW = (TPW - 1) * SI + KS;
     constexpr int XN = XH * XW * 8;                  // 16-byte slots of the x patch (8 per pixel: 64 channels)
     constexpr int XJ = (XN + 255) / 256;
     constexpr int DN = TPH * TPW * 8;                // 16-byte slots of the dy patch
@@ -302,9 +305,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH
         }
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -343,8 +346,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH
                 fa = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int kh = t / 3, kw = t - kh * 3;
+            for (int t = 0; t < NT; ++t) {
+                const int kh = t / KS, kw = t - kh * KS;
                 const int off0 = ((2 * s * SI + kh) * XW + kw) * LDX;
                 const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0));
                 const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(Xs + xlane + off0 + 4 * SI * LDX));
@@ -354,15 +357,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_bf16_kernel(const Wgrad3ArgsH
         }
     }
 
-    float* part = a.part + (size_t)blockIdx.y * a.N * 9 * a.C;
+    float* part = a.part + (size_t)blockIdx.y * a.N * NT * a.C;
     const int c = c0 + wc * 32 + (lane & 31);
     if (c < a.C) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (n < a.N) part[((size_t)n * 9 + t) * a.C + c] = acc[t][r];
+                if (n < a.N) part[((size_t)n * NT + t) * a.C + c] = acc[t][r];
             }
     }
 }
@@ -549,6 +552,36 @@ int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const 
     if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_S1>), dim3(tiles, ns), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_S2>), dim3(tiles, ns), dim3(256), 0, s, a);
     int err = (int)hipGetLastError();
+    if (err || direct) return err;
+    return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);
+}
+
+// 1x1 weight gradient (stride 1 or 2): 16 x 8 pixel patches (one tap of MFMA work per 16-pixel K step, so taller patches)
+#define TPH_1X1 16
+#define TPH_1X1_S2 8          // stride 2: the x patch is (2 TPH - 1) x 15 pixels
+size_t wgrad1x1_bf16_ws_bytes(int B, int OH, int OW, int N, int C) {
+    size_t m = 0;
+    for (int tph : {TPH_1X1, TPH_1X1_S2}) {
+        int ns, per, npy, npx;
+        wgrad3x3_plan_tph(tph, B, OH, OW, N, C, &ns, &per, &npy, &npx);
+        const size_t b = (size_t)ns * N * C * sizeof(float);
+        if (b > m) m = b;
+    }
+    return m;
+}
+
+int launch_wgrad1x1_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+    int ns, per;
+    wgrad3x3_plan_tph(stride == 1 ? TPH_1X1 : TPH_1X1_S2, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
+    const size_t nout = (size_t)a.N * a.C;
+    const bool direct = (ns == 1 && reg == 0.f);
+    if (!direct && ws_bytes < (size_t)ns * nout * sizeof(float)) return UNETRIR_EINVAL;
+    a.part = direct ? dw : (float*)ws;
+    a.patches_per_split = per;
+    const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
+    if (stride == 1) hipLaunchKernelGGL((wgrad3x3_bf16_kernel<1, TPH_1X1, 1, 1>), dim3(tiles, ns), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad3x3_bf16_kernel<2, TPH_1X1_S2, 1, 1>), dim3(tiles, ns), dim3(256), 0, s, a);
+    const int err = (int)hipGetLastError();
     if (err || direct) return err;
     return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);
 }

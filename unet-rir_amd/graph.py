@@ -1,5 +1,9 @@
-"""A small static-graph executor over the HIP kernels (fp32): the graph is built once as a list of (forward, backward)
+"""A small static-graph executor over the HIP kernels: the graph is built once as a list of (forward, backward)
 closures over preallocated NHWC buffers; forward runs the list, backward runs it in reverse.
+
+Two storage modes, as engine.UNetEngine: "f32" (everything fp32) and "bf16" (trunk activations, their gradients and the
+trunk kernels' work copies bf16; accumulation, BatchNorm statistics, biases, weight gradients, master weights, Adam and the
+Dense / Embedding branches fp32).  A convolution runs in the storage type of its INPUT node; `_cast` nodes join the two.
 
 Used for the operator graphs that are not hand-scheduled in engine.py: ResAE (dl_models/res_ae.py) and the U-Net feature
 block modes 1-3 (dl_models/u_net.py:324-386).  A tensor with several consumers gets its gradient from several writers:
@@ -32,10 +36,17 @@ class Node:
 
 
 class GraphEngine:
-    def __init__(self, B, device="cuda:0", n_replicas=1, runtime=None, share=None):
-        """share: another engine of the same class and configuration whose parameters, gradients, Adam moments, work copies
+    def __init__(self, B, device="cuda:0", n_replicas=1, runtime=None, share=None, dtype="f32"):
+        """dtype: storage type of the trunk ("f32" or "bf16").
+        share: another engine of the same class and configuration whose parameters, gradients, Adam moments, work copies
         and BatchNorm moving statistics this one aliases (only the activation buffers depend on the batch size)."""
         self.rt = runtime if runtime is not None else HipRuntime(device)
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
+        self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes (zero-padded 2-channel ends)
+        self._h_kernels = []                           # kernels of the convolutions that run in bf16 (work copies needed)
         self._share = share
         self._shared = share._shared if share is not None else {"adam_t": 0, "t_dirty": True, "dropout_step": 0}
         self.include_reg = True       # backward adds d/dw of the l2 terms (False: the caller differentiates them itself)
@@ -85,8 +96,23 @@ class GraphEngine:
         self._op_params.append([s_.name for s_ in self.specs_fwd[self._n_specs_seen:]])
         self._n_specs_seen = len(self.specs_fwd)
 
-    def _new(self, h, w, c, needs_grad=True):
-        return self._reg(Node(ops.new_act(self.B, h, w, c, self.device), needs_grad))
+    def _new(self, h, w, c, needs_grad=True, f32=False):
+        """A trunk activation (storage type of the engine) or, f32=True, a node of the fp32 branches."""
+        return self._reg(Node(ops.new_act(self.B, h, w, c, self.device, dtype=torch.float32 if f32 else self.adt), needs_grad))
+
+    def _cast(self, x: Node):
+        """The same tensor in the other storage type (fp32 <-> bf16 seam between a Dense branch and the trunk)."""
+        to16 = x.a.sfx == "f32"
+        y = self._reg(Node(ops.new_act(self.B, x.a.H, x.a.W, x.a.C, self.device, dtype=torch.bfloat16 if to16 else torch.float32)))
+
+        def fwd():
+            (ops.cast_f32_to_bf16 if to16 else ops.cast_bf16_to_f32)(x.a, y.a)
+
+        def bwd():
+            (ops.cast_bf16_to_f32 if to16 else ops.cast_f32_to_bf16)(y.g, x.g)
+            x.g_set = True
+        self._push(fwd, bwd)
+        return y
 
     def _view(self, parent: Node, c0, c):
         """Channel slice [c0, c0+c) of a buffer (one half of a skip concat)."""
@@ -112,8 +138,13 @@ class GraphEngine:
         else:
             H, W = -(-x.a.H // stride), -(-x.a.W // stride)
         co = pad_out if pad_out else cout
-        y = out if out is not None else self._new(H, W, co)
+        h16 = x.a.sfx == "bf16"           # the convolution runs in the storage type of its input
+        if dense and h16:
+            raise ValueError("Dense layers run in fp32: cast the input first")
+        y = out if out is not None else self._new(H, W, co, f32=not h16)
         kname, bname = name + ".kernel", name + ".bias"
+        if h16:
+            self._h_kernels.append(kname)
         real_in = 2 if pad_in else cin
         if transpose:      # primary layout [Cin][k][k][Cout]; keras (k,k,Cout,Cin)
             self._param(kname, (cin, k, k, co), "convT_padout" if pad_out else "convT", (k, k, cout, real_in), l2)
@@ -123,6 +154,9 @@ class GraphEngine:
         self._param(bname, (co,), "bias_pad" if pad_out else "bias", (cout,))
         g = ops.geom(B, x.a.H, x.a.W, cin, co, k, stride)
         reg = lambda: (2.0 * L2_COEF / self.n_replicas) if (l2 and self.include_reg) else 0.0
+
+        wf = (lambda: self._ph[kname]) if h16 else (lambda: self._p[kname])       # kernel as stored ([N][T][C])
+        wb = (lambda: self._pth[kname]) if h16 else (lambda: self._pt[kname])     # channel roles swapped ([C][T][N])
 
         def dense_dgrad(dst, add):
             if add is None:      # split-K path: the weight matrix streams from every CU
@@ -134,9 +168,9 @@ class GraphEngine:
             if dense:
                 ops.dense_fwd(x.a, self._p[kname], self._p[bname], y.a, self.ws)
             elif transpose:
-                ops.conv2d_transpose_fwd(g, x.a, self._pt[kname], self._p[bname], y.a)
+                ops.conv2d_transpose_fwd(g, x.a, wb(), self._p[bname], y.a)
             else:
-                ops.conv2d_fwd(g, x.a, self._p[kname], self._p[bname], y.a)
+                ops.conv2d_fwd(g, x.a, wf(), self._p[bname], y.a)
 
         def bwd():
             if transpose:
@@ -148,16 +182,49 @@ class GraphEngine:
             if dense:
                 self._emit(x, dense_dgrad)
             elif transpose:
-                self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, self._p[kname], dst, addend=add))
+                self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, wf(), dst, addend=add))
             else:
-                self._emit(x, lambda dst, add: ops.conv2d_dgrad(g, y.g, self._pt[kname], dst, addend=add))
+                self._emit(x, lambda dst, add: ops.conv2d_dgrad(g, y.g, wb(), dst, addend=add))
+        self._push(fwd, bwd)
+        return y
+
+    def _head6x6(self, x: Node, name):
+        """Conv2D(2, (6,6), 'same') in front of the sigmoid (dl_models/u_net.py:248).  fp32 trunk: an ordinary conv node with the
+        2 output channels padded to 4.  bf16 trunk: the head kernels of engine.UNetEngine - bf16 activations in, fp32 logits
+        [.., 4] out, bf16 dL/dlogits [.., 8] back."""
+        if x.a.sfx == "f32":
+            return self._conv(x, name, 2, 6, 1, followed_by_bn=False, pad_out=4, l2=False)
+        B, H, W, c, PAD = self.B, x.a.H, x.a.W, x.a.C, self.PAD
+        if not ops.head6x6_supported(c):
+            raise ValueError("the bf16 head needs number_filters_0 % 8 == 0")
+        kname, bname = name + ".kernel", name + ".bias"
+        self._param(kname, (PAD, 6, 6, c), "conv_padout", (6, 6, c, 2))
+        self._param(bname, (PAD,), "bias_pad", (2,))
+        self._h_kernels.append(kname)
+        y = self._reg(Node(ops.new_act(B, H, W, 4, self.device), True, ops.new_act(B, H, W, PAD, self.device, dtype=self.adt)))
+        g = ops.geom(B, H, W, c, PAD, 6, 1)
+        self.ws.reserve(512 * 2 * 36 * c * 4)
+
+        def fwd():
+            ops.head6x6_fwd(x.a, self._p[kname], self._p[bname], y.a)
+
+        def dgrad(dst, add):
+            if add is None and ops.head6x6_dgrad_supported(W, c):
+                ops.head6x6_dgrad(y.g, self._p[kname], dst)
+            else:
+                ops.conv2d_dgrad(g, y.g, self._pth[kname], dst, addend=add)
+
+        def bwd():
+            ops.head6x6_wgrad(x.a, y.g, self._g[kname], self.ws)          # rows 2.. of the padded kernel gradient stay 0
+            ops.colsum(y.g, self._g[bname], self.ws)
+            self._emit(x, dgrad)
         self._push(fwd, bwd)
         return y
 
     def _bn_act(self, x: Node, name, act, addend: Node = None, out: Node = None, batchnorm=True):
         """BatchNormalization (+ Add) (+ activation).  x must have this op as its only consumer."""
         c = x.a.C
-        y = out if out is not None else self._new(x.a.H, x.a.W, c)
+        y = out if out is not None else self._new(x.a.H, x.a.W, c, f32=x.a.sfx == "f32")
         if batchnorm:
             self._param(name + ".gamma", (c,), "gamma", (c,))
             self._param(name + ".beta", (c,), "beta", (c,))
@@ -201,14 +268,28 @@ class GraphEngine:
 
     def _add(self, x: Node, y: Node, out: Node = None):
         """Add()([x, y]) without activation (dl_models/u_net.py:229, :337, :359)."""
-        z = out if out is not None else self._new(x.a.H, x.a.W, x.a.C)
+        z = out if out is not None else self._new(x.a.H, x.a.W, x.a.C, f32=x.a.sfx == "f32")
+        mixed = x.a.sfx != y.a.sfx                # bf16 trunk + fp32 information-vector branch (dl_models/u_net.py:229)
+        if mixed and not (x.a.sfx == "bf16" and y.a.sfx == "f32"):
+            raise ValueError("mixed Add: the first operand is the bf16 trunk, the second the fp32 branch")
 
         def fwd():
-            ops.bn_act_add(x.a, None, z.a, 0, y.a)
+            if mixed:
+                ops.add_f32_to_bf16(x.a, y.a, z.a)
+            else:
+                ops.bn_act_add(x.a, None, z.a, 0, y.a)
+
+        def y_grad(dst, add):
+            if not mixed:
+                ops.bn_act_add(z.g, None, dst, 0, add)
+            elif add is None:
+                ops.cast_bf16_to_f32(z.g, dst)
+            else:
+                raise NotImplementedError("the fp32 operand of a mixed Add has one consumer")
 
         def bwd():
             self._emit(x, lambda dst, add: ops.bn_act_add(z.g, None, dst, 0, add))
-            self._emit(y, lambda dst, add: ops.bn_act_add(z.g, None, dst, 0, add))
+            self._emit(y, y_grad)
         self._push(fwd, bwd)
         return z
 
@@ -217,7 +298,9 @@ class GraphEngine:
 
     def _dropout(self, x: Node, which):
         """Dropout(.3) with an externally supplied keep mask self.masks[which] (already scaled by 1/(1-p))."""
-        y = self._new(x.a.H, x.a.W, x.a.C)
+        y = self._new(x.a.H, x.a.W, x.a.C, f32=x.a.sfx == "f32")
+        if x.a.sfx != "f32":
+            raise ValueError("Dropout sits on the fp32 Dense branches")
         self.masks.setdefault(which, None)
 
         def fwd():
@@ -300,11 +383,33 @@ class GraphEngine:
             k_ = self.specs[n].numel
             self._pt[n] = self.theta_t[o:o + k_]
             o += -(-k_ // ALIGN) * ALIGN
+        # bf16 work copies (both orientations) of the kernels whose convolution runs in bf16
+        self._ph, self._pth, self._cast_table = {}, {}, None
+        if self._h_kernels:
+            hoff = sum(-(-self.specs[n].numel // ALIGN) * ALIGN for n in self._h_kernels)
+            self.theta_h = sh.theta_h if sh is not None else torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
+            self.theta_th = sh.theta_th if sh is not None else torch.zeros(max(hoff, 8), dtype=torch.bfloat16, device=dev)
+            o = 0
+            for n in self._h_kernels:
+                k_ = self.specs[n].numel
+                self._ph[n], self._pth[n] = self.theta_h[o:o + k_], self.theta_th[o:o + k_]
+                o += -(-k_ // ALIGN) * ALIGN
 
     def refresh_transposed(self):
         for n in self._tnames:
+            if n in self._ph:
+                continue                                    # bf16 path: both work copies come from the cast below
             s_ = self.specs[n]
             ops.transpose_weight(self._p[n], self._pt[n], s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3])
+        if self._ph:
+            if self._cast_table is None:
+                ent = []
+                for n in self._ph:
+                    s_ = self.specs[n]
+                    N, T, C_ = s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3]
+                    ent.append((self._p[n], self._ph[n], self._pth[n], N, T, C_, C_, N))
+                self._cast_table = ops.make_cast_table(ent, self.device)
+            ops.cast_weights_batched(self._cast_table)
 
     def load_keras_params(self, params):
         """params: name -> array in Keras layout (HWIO Conv2D, HWOI Conv2DTranspose, [in,out] Dense)."""
@@ -403,12 +508,18 @@ class GraphEngine:
             node.g_set = False
 
     def loss_or_sigmoid(self, logits: Node, target, global_batch, alpha):
+        la = logits.a
+        if la.sfx == "bf16":          # a bf16 output layer (ResAE / Autoencoder): the sigmoid + loss kernel reads fp32 logits
+            if self._logits32 is None:
+                self._logits32 = ops.new_act(self.B, la.H, la.W, la.ld, self.device)
+            ops.cast_bf16_to_f32(la, self._logits32)
+            la = self._logits32
         if target is not None:
             gb = self.B if global_batch is None else global_batch
-            ops.sigmoid_loss(logits.a, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, logits.g, self.loss_out, self.ws)
+            ops.sigmoid_loss(la, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, logits.g, self.loss_out, self.ws)
             logits.g_set = True
         else:
-            ops.sigmoid_nchw(logits.a, self.pred)
+            ops.sigmoid_nchw(la, self.pred)
         return self.pred
 
     def loss_from_logits(self, target, global_batch=None, alpha=0.9):
@@ -425,6 +536,7 @@ class GraphEngine:
     def _alloc_outputs(self):
         dev = self.device
         self.loss_tot = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._logits32 = None
         self.pred = torch.empty((self.B, 2, self.H, self.W), dtype=torch.float32, device=dev)
         self.loss_out = torch.zeros(4, dtype=torch.float32, device=dev)
         self.reg_out = torch.zeros(1, dtype=torch.float32, device=dev)

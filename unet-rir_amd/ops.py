@@ -223,6 +223,10 @@ def add_f32_to_bf16(a: Act, b: Act, y: Act):
     check(_lib.lib().unetrir_add_f32_to_bf16(_p(a), _p(b), _p(y), a.base.numel(), _stream()), "add_f32_to_bf16")
 
 
+def cast_f32_to_bf16(a: Act, y: Act):
+    check(_lib.lib().unetrir_cast_f32_to_bf16(_p(a), _p(y), a.base.numel(), _stream()), "cast_f32_to_bf16")
+
+
 def cast_bf16_to_f32(a: Act, y: Act):
     check(_lib.lib().unetrir_cast_bf16_to_f32(_p(a), _p(y), a.base.numel(), _stream()), "cast_bf16_to_f32")
 
@@ -267,13 +271,12 @@ def bn_inference_affine(gamma, beta, moving_mean, moving_var, eps, affine):
 
 def bn_act_add(x: Act, affine, y: Act, act=2, addend: Act = None):
     """BatchNormalization -> Add -> activation (dl_models/res_ae.py:331-336); act 0 none, 1 ReLU, 2 LeakyReLU(0.3)."""
-    check(_lib.lib().unetrir_bn_act_add_f32(_p(x), x.ld, x.P, x.C, _p(affine), int(act), _p(addend),
-                                            addend.ld if addend is not None else 0, _p(y), y.ld, _stream()), "bn_act_add")
+    check(_fn("bn_act_add", x.sfx)(_p(x), x.ld, x.P, x.C, _p(affine), int(act), _p(addend),
+                                   addend.ld if addend is not None else 0, _p(y), y.ld, _stream()), "bn_act_add")
 
 
 def act_bwd(da: Act, out: Act, g: Act, act=2):
-    check(_lib.lib().unetrir_act_bwd_f32(_p(da), da.ld, _p(out), out.ld, out.P, out.C, int(act), _p(g), g.ld, _stream()),
-          "act_bwd")
+    check(_fn("act_bwd", out.sfx)(_p(da), da.ld, _p(out), out.ld, out.P, out.C, int(act), _p(g), g.ld, _stream()), "act_bwd")
 
 
 def add(a, b, y):

@@ -15,8 +15,8 @@ class ResAEEngine(GraphEngine):
     """One replica of ResAE for a fixed per-replica batch size (constructor mirrors dl_models/res_ae.py:41-50)."""
 
     def __init__(self, H, W, B, conv_filters=(32, 64, 128, 256), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
-                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None, share=None):
-        super().__init__(B, device, n_replicas, runtime, share)
+                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None, share=None, dtype="f32"):
+        super().__init__(B, device, n_replicas, runtime, share, dtype)
         self.H, self.W = H, W
         self.filters, self.kernels, self.strides = tuple(conv_filters), tuple(conv_kernels), tuple(conv_strides)
         if any(f % 4 for f in self.filters) or any(s not in (1, 2) for s in self.strides):
@@ -49,10 +49,10 @@ class ResAEEngine(GraphEngine):
         """dl_models/res_ae.py:210-530."""
         B, dev = self.B, self.device
         n = len(self.filters)
-        self.x4 = self._reg(Node(ops.new_act(B, self.H, self.W, 4, dev), needs_grad=False))
+        self.x4 = self._reg(Node(ops.new_act(B, self.H, self.W, self.PAD, dev, dtype=self.adt), needs_grad=False))
         x = self.x4
         for i in range(n):        # encoder: _add_conv_layers (:424-451)
-            x = self._res_block(x, f"e_res_{i + 1}", self.filters[i], self.kernels[i], self.strides[i], False, True, pad_in=4 if i == 0 else 0)
+            x = self._res_block(x, f"e_res_{i + 1}", self.filters[i], self.kernels[i], self.strides[i], False, True, pad_in=self.PAD if i == 0 else 0)
             x = self._res_block(x, f"e_res_{i + 1}", self.filters[i], self.kernels[i], 1, False, False)
         h, w, c = x.a.H, x.a.W, x.a.C
         self.shape_before_bottleneck = (h, w, c)
@@ -60,7 +60,7 @@ class ResAEEngine(GraphEngine):
         flat_vec = self._embedding(self.n_idx)                  # Embedding -> Flatten (:411-420)
         vec = self._dense(flat_vec, "e_dense_vector", self.n_neurons)
         # concatenate([Flatten(x), vec]) -> Dense(latent) -> Dropout (:516-530); the concat is a copy of two row blocks
-        cat = self._new(1, 1, n_feat + self.n_neurons)
+        cat = self._new(1, 1, n_feat + self.n_neurons, f32=True)     # fp32 (the copies below convert the trunk half)
         x_last = x
 
         def cat_fwd():
@@ -77,6 +77,8 @@ class ResAEEngine(GraphEngine):
         d = self._dense(zd, "decoder_dense", n_feat)             # decoder: Dense -> Dropout -> Reshape (:247-268)
         dd = self._dropout(d, "dec")
         x = self._reshape(dd, h, w, c)
+        if self.dtype == "bf16":
+            x = self._cast(x)                                  # the Dense branch is fp32, the transposed-conv trunk bf16
         x = self._res_block(x, "d_res_0", self.filters[-1], self.kernels[-1], 1, True, True)
         x = self._res_block(x, "d_res_0", self.filters[-1], self.kernels[-1], 1, True, False)
         for layer_index in reversed(range(1, n)):                # _add_conv_transpose_layers (:272-308)
@@ -85,7 +87,7 @@ class ResAEEngine(GraphEngine):
             x = self._res_block(x, name, f, k, self.strides[layer_index - 1], True, True)
             x = self._res_block(x, name, f, k, 1, True, False)
         # _add_decoder_output (:373-389): Conv2DTranspose(2, k0, s0, 'same') + sigmoid; Cout padded 2 -> 4
-        self.logits = self._conv(x, "d_out", 2, self.kernels[0], self.strides[0], True, followed_by_bn=False, pad_out=4, l2=False)
+        self.logits = self._conv(x, "d_out", 2, self.kernels[0], self.strides[0], True, followed_by_bn=False, pad_out=self.PAD, l2=False)
         if (self.logits.a.H, self.logits.a.W) != (self.H, self.W):
             raise ValueError("decoder output size does not match the input size")
 

@@ -1,4 +1,4 @@
-"""The U-Net of dl_models/u_net.py with every feature-block mode (0-3) on graph.GraphEngine (fp32).
+"""The U-Net of dl_models/u_net.py with every feature-block mode (0-3) on graph.GraphEngine (fp32 or bf16 storage).
 
 engine.UNetEngine is the hand-scheduled fast path for mode 0 (the only mode the live driver and every BASELINE config
 use); this engine covers mode 1 (convolutional_block_2), mode 2 (residual_block_1) and mode 3 (residual_block_2)
@@ -15,12 +15,12 @@ from .engine import VEC_CH, EMB_DIM
 
 class UNetGraphEngine(GraphEngine):
     def __init__(self, H, W, B, F0=32, k=3, depth=4, mode=0, batchnorm=True, inf_vector_shape=(2, 16), device="cuda:0",
-                 n_replicas=1, runtime=None, share=None):
-        super().__init__(B, device, n_replicas, runtime, share)
+                 n_replicas=1, runtime=None, share=None, dtype="f32"):
+        super().__init__(B, device, n_replicas, runtime, share, dtype)
         if mode not in (0, 1, 2, 3):
             raise ValueError("mode must be 0..3")
-        if F0 % 4:
-            raise ValueError("number_filters_0 must be a multiple of 4")
+        if F0 % self.PAD:
+            raise ValueError(f"number_filters_0 must be a multiple of {self.PAD} for dtype {dtype}")
         self.H, self.W, self.F0, self.k, self.depth, self.mode, self.batchnorm = H, W, F0, k, depth, mode, batchnorm
         self.inf_vector_shape = tuple(inf_vector_shape)
         self.n_idx = int(math.prod(self.inf_vector_shape))
@@ -54,13 +54,13 @@ class UNetGraphEngine(GraphEngine):
     def _build(self):
         """UNet._build (dl_models/u_net.py:201-251)."""
         B, dev, D, ch, k = self.B, self.device, self.depth, self.ch, self.k
-        self.x4 = self._reg(Node(ops.new_act(B, self.H, self.W, 4, dev), needs_grad=False))
+        self.x4 = self._reg(Node(ops.new_act(B, self.H, self.W, self.PAD, dev, dtype=self.adt), needs_grad=False))
         x, h, w = self.x4, self.H, self.W
         skips, cats = [], []
         for l in range(1, D + 2):
             c = ch[l - 1]
             stride = 1 if l == 1 else 2
-            d = self._conv(x, f"enc{l}.down", c, k, stride, followed_by_bn=False, pad_in=4 if l == 1 else 0, l2=True)
+            d = self._conv(x, f"enc{l}.down", c, k, stride, followed_by_bn=False, pad_in=self.PAD if l == 1 else 0, l2=True)
             h, w = d.a.H, d.a.W
             if l <= D:         # the block output is the skip: written straight into the lower half of the concat buffer
                 cat = self._new(h, w, 2 * c)
@@ -83,7 +83,7 @@ class UNetGraphEngine(GraphEngine):
             self._conv(x, f"dec{l}.up", c, k, 2, transpose=True, followed_by_bn=False, out=up, l2=True)
             a = self._conv_bn_relu(cat, f"dec{l}.cb1a", c, k)
             x = self._feature_block(a, f"dec{l}")
-        self.logits = self._conv(x, "head", 2, 6, 1, followed_by_bn=False, pad_out=4, l2=False)
+        self.logits = self._head6x6(x, "head")
         self.vec_dim = h5 * w5 * VEC_CH      # l2(0.001) sits only on the strided and the transposed convs (:274, :302)
 
     def make_dropout_mask(self, generator=None):
