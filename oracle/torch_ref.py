@@ -253,10 +253,10 @@ def conv_block_1(x, P, name, cfg, state, training, inter, q=_ident, qw=_ident):
     if inter is not None:
         inter[name + ".conv"] = y
     if cfg.batchnorm:
-        y = bn_relu(y, P[name + ".gamma"], P[name + ".beta"], state, name, training)
-    else:
-        y = F.relu(y)
-    y = q(y)
+        y = bn_relu(y, P[name + ".gamma"], P[name + ".beta"], state, name, training, relu=False)
+    if inter is not None:
+        inter[name + ".pre"] = y                         # the ReLU input (tests: distance of the nearest one from zero)
+    y = q(F.relu(y))
     if inter is not None:
         inter[name + ".out"] = y
     return y

@@ -23,10 +23,10 @@ def U():
     return unet_rir_amd
 
 
-def run_case(U, H, W, F0, B, batchnorm=True, dropout=False, k=3, depth=4, world=1):
+def run_case(U, H, W, F0, B, batchnorm=True, dropout=False, k=3, depth=4, world=1, seed="d"):
     cfg = R.Config(H, W, F0, k, depth, batchnorm)
     Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
-    spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, B, seed_name=seed)
     mask = None
     h5, w5 = cfg.bottleneck_hw()
     if dropout:
@@ -89,11 +89,15 @@ def test_forward_backward_vs_oracle(U, H, W, F0, B, bn, do):
 
 def test_reference_geometry_144x160(U):
     """The reference's own spatial size (main_training.py:27): 144x160 -> 9x10 bottleneck (odd size after the last stride)."""
-    cfg, Pn, eng, tr, ref, _ = run_case(U, 144, 160, 4, 1)
-    worst = check_against_oracle(eng, ref, max_tol=2e-2, l2_tol=1e-2)
-    # everything computed before the flipped element (the whole decoder and enc5/enc4) is at fp32 round-off
-    assert max(v for n, v in worst.items() if n.startswith(("dec", "head", "enc5", "enc4.")) and not n.endswith("cb1.bias")
-               and not n.endswith("cb1a.bias") and not n.endswith("cb1b.bias")) <= 1e-4
+    # 4.6e5 ReLU inputs of O(1): with an arbitrary input the nearest one to zero is ~1e-7 away, inside fp32 round-off of the
+    # BatchNorm output, and takes the other branch than in the fp64 oracle (one element, seen with the default data seed in
+    # round 1).  This data seed keeps every ReLU input of the oracle >= 5e-6 from zero - checked here - so no branch can flip
+    # and the case runs at the standard tolerances, encoder included.
+    cfg, Pn, eng, tr, ref, _ = run_case(U, 144, 160, 4, 1, seed="g1")
+    inter = ref[4]
+    nearest = min(float(v.abs().min()) for n, v in inter.items() if n.endswith(".pre"))
+    assert nearest >= 5e-6, nearest
+    check_against_oracle(eng, ref)
 
 
 def test_adam_step_and_two_replica_scaling(U):
@@ -380,8 +384,15 @@ def test_checkpoint_resume_and_epoch_loop(U, tmp_path):
     hist = U.fit(tr2, lambda e: [batch, batch], 3, val_batches=lambda e: [batch], manager=mgr2, lr0=0.0, log=None)
     assert [h["epoch"] for h in hist] == [1, 2, 3] and "checkpoint" in hist[0] and "checkpoint" not in hist[1]
     assert all(np.isfinite(h[k]) for h in hist for k in ("train_loss", "train_amp", "train_phase", "val_loss", "val_amp", "val_phase"))
-    assert abs(hist[0]["train_loss"] - (0.9 * hist[0]["train_amp"] + 0.1 * hist[0]["train_phase"])) < 1e-5
-    assert torch.equal(eng2.theta, before)                         # lr 0: nothing moved, validation updates nothing
+    # the reference's definitions (main_training.py:203-235, :239-244): loss = (0.9 mean_amp + 0.1 mean_phase) / 2 + l2 terms,
+    # with mean_* the tf.keras.metrics.Mean over every (b, h, w) element
+    eng2.reg_loss()
+    reg = float(eng2.reg_out[0])
+    assert reg > 0
+    assert abs(hist[0]["train_loss"] - reg - 0.5 * (0.9 * hist[0]["train_amp"] + 0.1 * hist[0]["train_phase"])) < 1e-5
+    amp_mean = float(((batch[2][:, 0] - eng2.pred[:, 0]) ** 2).mean())        # the validation pass was the last forward
+    assert abs(hist[-1]["val_amp"] - amp_mean) <= 1e-5 * amp_mean
+    assert torch.equal(eng2.theta, before)                         # lr 0: no variable moved
     assert U.lr_schedule(1e-3, 79) == 1e-3 and abs(U.lr_schedule(1e-3, 80) - 1e-3 * 0.9) < 1e-12
 
 

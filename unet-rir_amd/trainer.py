@@ -311,38 +311,59 @@ class CheckpointManager:
 
 
 def fit(trainer: "Trainer", train_batches, n_epochs, val_batches=None, manager: CheckpointManager = None, lr0=None,
-        lr_exp_decay=(True, 80), start_epoch=0, log=print):
+        lr_exp_decay=(True, 80), start_epoch=0, log=print, val_updates_moving=True):
     """The epoch loop of main_training.py:336-390: exponential rate from epoch 80, running means of the amplitude / phase
     loss terms, a checkpoint every second epoch.  `train_batches` / `val_batches` are callables returning an iterable of
-    (spec_in, emb, spec_out) per-replica shards for the epoch.  As in the reference the validation pass runs the model
-    with training=True semantics (main_training.py:297-300: batch statistics, dropout active) but updates nothing."""
+    (spec_in, emb, spec_out) per-replica shards for the epoch.
+
+    Reported values are the reference's: `train_loss` = mean over steps of the cross-replica SUM of the per-replica loss
+    (data term / global batch + l2 terms / replicas: strategy.reduce(SUM, ...), main_training.py:323-327, :345-352);
+    `*_amp` / `*_phase` = tf.keras.metrics.Mean over every (b, h, w) element of (a - a^)^2 and 1 - cos(...) across steps and
+    replicas (main_training.py:239-244, :279-284).  The validation pass calls the model with training=True as the reference's
+    test_step does (main_training.py:297-300): batch statistics, dropout active - and, as in Keras, the BatchNorm moving
+    statistics move during it (`val_updates_moving=False` keeps them at their post-training values instead)."""
     eng = trainer.engine
     lr0 = trainer.lr if lr0 is None else lr0
-    inv = 1.0 / (2.0 * eng.H * eng.W * eng.B * trainer.world_size)      # loss_out[1:3] are raw sums of the two terms
+    per_elem = 1.0 / (eng.H * eng.W * eng.B * trainer.world_size)       # loss_out[1:3] are raw per-replica sums of the two terms
     history = []
+
+    def reduce_(t):
+        if trainer.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=trainer.group)
+        return t.double().cpu()
+
     for epoch in range(start_epoch, n_epochs):
         lr = lr_schedule(lr0, epoch, lr_exp_decay)
-        tot = torch.zeros(3, dtype=torch.float64)
+        tot = torch.zeros(4, dtype=torch.float32, device=eng.device)      # data loss, amplitude sum, phase sum, l2 terms
         nb = 0
         for spec_in, emb, spec_out in train_batches(epoch):
             trainer.step(spec_in, emb, spec_out, lr=lr)
-            tot += eng.loss_out[:3].double().cpu()          # total data loss, amplitude term, phase term of this step
+            tot[:3] += eng.loss_out[:3]          # total data loss, amplitude term, phase term of this step
             nb += 1
-        rec = {"epoch": epoch + 1, "lr": lr, "train_loss": float(tot[0]) / max(nb, 1), "train_amp": float(tot[1]) * inv / max(nb, 1),
-               "train_phase": float(tot[2]) * inv / max(nb, 1)}
+        # the l2 terms at the end of the epoch stand for every step's (they move by lr * 2e-3 * w per step: below fp32 resolution
+        # of the reported mean); evaluated once instead of 9 reductions per step
+        eng.reg_loss()
+        tot[3] = eng.reg_out[0] * max(nb, 1)
+        tot = reduce_(tot)
+        n = max(nb, 1)
+        rec = {"epoch": epoch + 1, "lr": lr, "train_loss": float(tot[0] + tot[3]) / n,
+               "train_amp": float(tot[1]) * per_elem / n, "train_phase": float(tot[2]) * per_elem / n}
         if val_batches is not None:
-            vt = torch.zeros(3, dtype=torch.float64)
+            vt = torch.zeros(3, dtype=torch.float32, device=eng.device)
             vb = 0
-            saved_moving = {k: v.clone() for k, v in eng.moving.items()}
+            saved_moving = None if val_updates_moving else {k: v.clone() for k, v in eng.moving.items()}
             for spec_in, emb, spec_out in val_batches(epoch):
                 eng.training = True
                 mask = eng.make_dropout_mask() if trainer.dropout else None
                 eng.forward(spec_in, emb, dropout_mask=mask, target=spec_out, global_batch=eng.B * trainer.world_size, alpha=trainer.alpha)
-                vt += eng.loss_out[:3].double().cpu()
+                vt += eng.loss_out[:3]
                 vb += 1
-            for k, v in saved_moving.items():                # a forward in training mode moved the BN averages: undo
-                eng.moving[k].copy_(v)
-            rec.update(val_loss=float(vt[0]) / max(vb, 1), val_amp=float(vt[1]) * inv / max(vb, 1), val_phase=float(vt[2]) * inv / max(vb, 1))
+            if saved_moving is not None:
+                for k, v in saved_moving.items():
+                    eng.moving[k].copy_(v)
+            vt = reduce_(vt)
+            m = max(vb, 1)
+            rec.update(val_loss=float(vt[0]) / m, val_amp=float(vt[1]) * per_elem / m, val_phase=float(vt[2]) * per_elem / m)
         if manager is not None and epoch % 2 == 0:
             rec["checkpoint"] = manager.save(epoch=epoch)
         history.append(rec)
