@@ -67,9 +67,11 @@ int unetrir_abi_version(void);
  *        upconv3x3g     UNETRIR_UPCONV3X3G     bf16 LDS-DMA transposed / strided-dgrad kernel (upconv3x3g.hip)
  *        wgrad3x3g      UNETRIR_WGRAD3X3G      bf16 LDS-DMA 3x3 weight gradient (wgrad3x3g.hip)
  *        wgrad3x3r      UNETRIR_WGRAD3X3R      bf16 register-staged 3x3 weight gradient (wgrad3x3r.hip)
- *        head_mfma      UNETRIR_HEAD_MFMA      bf16 6x6 head on the matrix cores (head_mfma.hip) */
+ *        head_mfma      UNETRIR_HEAD_MFMA      bf16 6x6 head on the matrix cores (head_mfma.hip)
+ *        wgrad3x3d      UNETRIR_WGRAD3X3D      bf16 LDS-DMA 3x3 stride-2 weight gradient (wgrad3x3d.hip) */
 typedef struct {
-    int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma;
+    int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
+        wgrad3x3d;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);

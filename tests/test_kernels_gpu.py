@@ -320,6 +320,7 @@ BF16_CONV_CASES = [
     (2, 24, 70, 48, 160, 3, 1), (1, 40, 64, 136, 64, 3, 1),          # patch-staged kernel: multi-tile, ragged, 3 chunks
     (2, 32, 72, 40, 72, 3, 2),                                        # stride 2: fused parity-class data gradient
     (1, 32, 64, 24, 64, 3, 2),                                        # stride 2: data gradient on upconv3x3g (C = 64 output channels)
+    (2, 32, 64, 64, 128, 3, 2), (2, 16, 64, 136, 72, 3, 2), (3, 24, 32, 32, 160, 3, 2),   # stride 2: weight gradient on wgrad3x3d (LDS-DMA; one tile / ragged channel tails / several n tiles)
     (2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1),            # LDS-DMA kernel (conv3x3g): ragged tiles / channels, 3 chunks
     (3, 16, 16, 64, 160, 3, 1), (4, 16, 16, 96, 128, 3, 1), (2, 32, 16, 64, 128, 3, 1), (5, 9, 11, 32, 72, 3, 1),   # conv3x3g, two narrow images per tile (odd batch, ragged)
     (2, 32, 32, 128, 256, 3, 1),                                      # LDS-DMA kernel: forward 4 chunks, data gradient 8 chunks

@@ -23,6 +23,7 @@ unetrir_config load_config() {
     c.upconv3x3g = env_int("UNETRIR_UPCONV3X3G", 1);
     c.wgrad3x3g = env_int("UNETRIR_WGRAD3X3G", 1);
     c.wgrad3x3r = env_int("UNETRIR_WGRAD3X3R", 1);
+    c.wgrad3x3d = env_int("UNETRIR_WGRAD3X3D", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     return c;
 }

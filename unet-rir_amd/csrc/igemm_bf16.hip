@@ -540,6 +540,9 @@ int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const 
         if (err != WGRAD3X3R_NOT_TAKEN) return err;
         err = launch_wgrad3x3r_bf16(a, dw, reg, w, ws, ws_bytes, s);
         if (err != WGRAD3X3R_NOT_TAKEN) return err;
+    } else {                 // stride 2: LDS-DMA kernel with the column-de-interleaved x patch (wgrad3x3d.hip)
+        const int err = launch_wgrad3x3d_bf16(a, dw, reg, w, ws, ws_bytes, s);
+        if (err != WGRAD3X3R_NOT_TAKEN) return err;
     }
     int ns, per;
     wgrad3x3_plan_tph(stride == 1 ? TPH_S1 : TPH_S2, a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);

@@ -96,6 +96,9 @@ struct Wgrad3ArgsH {
 int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s);
 int launch_igemm_fwd_bf16_x4(const IgemmArgsH* a, hipStream_t s);
 int launch_wgrad3x3_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
+bool wgrad3x3d_applies(const Wgrad3ArgsH& a);       // stride 2, even sizes: LDS-DMA kernel with the de-interleaved x patch
+size_t wgrad3x3d_ws_bytes(int B, int OH, int OW, int N, int C);
+int launch_wgrad3x3d_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 size_t wgrad1x1_bf16_ws_bytes(int B, int OH, int OW, int N, int C);
 int launch_wgrad1x1_bf16(Wgrad3ArgsH a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
 #define WGRAD3X3R_NOT_TAKEN (-12345)

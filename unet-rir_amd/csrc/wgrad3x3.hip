@@ -143,7 +143,12 @@ void wgrad3x3_plan_tph(int TPH, int B, int OH, int OW, int N, int C, int* nsplit
 size_t wgrad3x3_ws_bytes(int stride, int B, int OH, int OW, int N, int C) {
     int ns, per, npy, npx;
     wgrad3x3_plan(stride, B, OH, OW, N, C, &ns, &per, &npy, &npx);
-    return (size_t)ns * N * 9 * C * sizeof(float);
+    size_t bytes = (size_t)ns * N * 9 * C * sizeof(float);
+    if (stride == 2) {                       // the bf16 LDS-DMA kernel (wgrad3x3d.hip) has its own split plan
+        const size_t d = wgrad3x3d_ws_bytes(B, OH, OW, N, C);
+        if (d > bytes) bytes = d;
+    }
+    return bytes;
 }
 
 int launch_wgrad3x3(Wgrad3Args a, int stride, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
