@@ -53,5 +53,11 @@ for (B, H, Ci, Co) in [(8, 64, 128, 64), (8, 32, 256, 128)]:
     wt = rnd((Co, 9, Ci), 0.1)
     out = ops.Act(torch.empty((B, 2 * H, 2 * H, Co), dtype=torch.bfloat16, device=dev))
     total += screen(f"convT fwd {Ci}->{Co} @{H}->{2*H}", lambda: ops.conv2d_transpose_fwd(g, x, wt, None, out), out.base)
+for (B, H, Ci, Co) in [(8, 128, 64, 128), (8, 64, 128, 256)]:          # stride-2 weight gradient: wgrad3x3d
+    g = ops.geom(B, H, H, Ci, Co, 3, 2)
+    x, y = ops.Act(rnd((B, H, H, Ci))), ops.Act(rnd((B, H // 2, H // 2, Co)))
+    dw = torch.empty((Co, 9, Ci), device=dev)
+    ws = ops.Workspace(dev)
+    total += screen(f"conv s2 wgrad {Ci}->{Co} @{H}", lambda: ops.conv2d_wgrad(g, x, y, dw, ws), dw)
 print("race screen:", "clean" if total == 0 else f"{total} failures")
 sys.exit(1 if total else 0)
