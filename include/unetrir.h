@@ -68,10 +68,11 @@ int unetrir_abi_version(void);
  *        wgrad3x3g      UNETRIR_WGRAD3X3G      bf16 LDS-DMA 3x3 weight gradient (wgrad3x3g.hip)
  *        wgrad3x3r      UNETRIR_WGRAD3X3R      bf16 register-staged 3x3 weight gradient (wgrad3x3r.hip)
  *        head_mfma      UNETRIR_HEAD_MFMA      bf16 6x6 head on the matrix cores (head_mfma.hip)
- *        wgrad3x3d      UNETRIR_WGRAD3X3D      bf16 LDS-DMA 3x3 stride-2 weight gradient (wgrad3x3d.hip) */
+ *        wgrad3x3d      UNETRIR_WGRAD3X3D      bf16 LDS-DMA 3x3 stride-2 weight gradient (wgrad3x3d.hip)
+ *        conv3x3d       UNETRIR_CONV3X3D       bf16 LDS-DMA 3x3 stride-2 forward / transposed data gradient (conv3x3d.hip) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d;
+        wgrad3x3d, conv3x3d;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);
@@ -250,6 +251,22 @@ int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetri
 int unetrir_conv2d_transpose_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx,
                                         const unetrir_bf16* dy, int lddy, float* dw, float reg_coef, const float* w,
                                         void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* The stride-2 3x3 forward kernel (conv3x3d.hip: strided Conv2D forward, Conv2DTranspose data gradient) streams its kernel
+ * 16 input channels at a time; from the [N][9][C] copy that is a gather of 32-byte pieces.  A PACKED copy holds the same values
+ * in the order the kernel's LDS-DMA reads them - [N / 128][C / 16][9 taps][4 blocks of 32 channels][64 lanes][8 values], lane =
+ * (row of the block, permuted as the MFMA accumulator layout wants it; 8-channel half) - so every DMA piece is 1 KB of
+ * contiguous memory (measured: 22-26 us of 100-160 per launch).  unetrir_cast_weights_batched_bf16 writes it when the
+ * descriptor carries a destination; the _packed entry points take it beside the plain copy (NULL: plain copy only).
+ * unetrir_conv3x3s2_packed_elems returns the element count of the packed copy, 0 where none is defined (N or C not a
+ * multiple of 64). */
+size_t unetrir_conv3x3s2_packed_elems(int N, int C);
+int unetrir_conv2d_fwd_packed_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
+                                   const unetrir_bf16* w_packed, const float* bias, const unetrir_bf16* addend, int ldadd,
+                                   unetrir_bf16* y, int ldy, unetrir_stream_t stream);
+int unetrir_conv2d_transpose_dgrad_packed_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy,
+                                               const unetrir_bf16* w, const unetrir_bf16* w_packed,
+                                               const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx,
+                                               unetrir_stream_t stream);
 /* fp32 master weights [N][T][C] -> bf16 work copies: same orientation with channels zero-padded to Cp; transposed
  * [C][T][Np] with the row dimension zero-padded to Np. */
 int unetrir_cast_weight_bf16(const float* w, unetrir_bf16* o, int N, int T, int C, int Cp, unetrir_stream_t stream);
@@ -262,6 +279,8 @@ typedef struct unetrir_cast_desc {
     unetrir_bf16* same;        /* bf16 [N][T][Cp] or NULL */
     unetrir_bf16* transposed;  /* bf16 [C][T][Np] or NULL */
     int N, T, C, Cp, Np, reserved;
+    unetrir_bf16* packed_s2;   /* 3x3 kernels served by the stride-2 forward kernel: a third copy in the order its LDS-DMA reads it
+                                  (unetrir_conv3x3s2_packed_elems(N, C) elements, zero-initialised by the caller), or NULL */
 } unetrir_cast_desc;
 int unetrir_cast_weights_batched_bf16(const unetrir_cast_desc* desc, int n_layers, unetrir_stream_t stream);
 int unetrir_bn_stats_bf16(const unetrir_bf16* x, int ldx, long long P, int C, const float* gamma, const float* beta,

@@ -59,7 +59,10 @@ class CpuOps:
     def _w_hwio(self, w, g):
         return w.reshape(g.Cout, g.k, g.k, g.Cin).to(D).permute(1, 2, 3, 0)
 
-    def conv2d_fwd(self, g, x, w, bias, y, addend=None):
+    def conv3x3s2_packed_elems(self, N, C_):
+        return 0                          # the simulated device has no packed kernel copies
+
+    def conv2d_fwd(self, g, x, w, bias, y, addend=None, w_packed=None):
         self.rt.touch([x, w, bias, addend], [y], "conv2d_fwd")
         out = R.conv2d_same(_nchw(x), self._w_hwio(w, g), None if bias is None else bias.to(D)[:g.Cout], g.stride)
         if addend is not None:
@@ -104,7 +107,7 @@ class CpuOps:
         k_hwoi = w_primary.reshape(g.Cin, g.k, g.k, g.Cout).permute(1, 2, 3, 0)
         return R.conv2d_transpose_same(x, k_hwoi, torch.zeros(g.Cout, dtype=D), g.stride)
 
-    def conv2d_transpose_dgrad(self, g, dy, w, dx, addend=None):
+    def conv2d_transpose_dgrad(self, g, dy, w, dx, addend=None, w_packed=None):
         self.rt.touch([dy, w, addend], [dx], "conv2d_transpose_dgrad")
         x0 = torch.zeros((g.B, g.Cin, g.H, g.W), dtype=D, requires_grad=True)
         (gx,) = torch.autograd.grad(self._convT(g, x0, w.to(D)), x0, _nchw(dy))
@@ -266,7 +269,7 @@ class CpuOps:
 
     def cast_weights_batched(self, table):
         ents, _ = table
-        for (w, same, tr, N, T, C_, Cp, Np) in ents:
+        for (w, same, tr, N, T, C_, Cp, Np, *_pk) in ents:
             self.rt.touch([w], [same, tr], "cast_weights")
             if same is not None:
                 same.reshape(N, T, Cp)[..., :C_] = w.reshape(N, T, C_).to(same.dtype)

@@ -23,7 +23,8 @@ def test_gpus2_self_launch_fails_loudly_without_gpus():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0
     assert "needs 2 visible GPUs" in r.stderr
-    assert "rank 0" in r.stderr and "rank 1" in r.stderr      # both children started and reported
+    assert "rank 0" in r.stderr or "rank 1" in r.stderr       # a child started and reported (the launcher ends the other one
+                                                               # as soon as the first has failed, possibly before it gets to print)
     assert r.stdout.strip() == ""                              # no JSON line from a failed run
 
 

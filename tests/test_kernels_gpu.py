@@ -321,6 +321,10 @@ BF16_CONV_CASES = [
     (2, 32, 72, 40, 72, 3, 2),                                        # stride 2: fused parity-class data gradient
     (1, 32, 64, 24, 64, 3, 2),                                        # stride 2: data gradient on upconv3x3g (C = 64 output channels)
     (2, 32, 64, 64, 128, 3, 2), (2, 16, 64, 136, 72, 3, 2), (3, 24, 32, 32, 160, 3, 2),   # stride 2: weight gradient on wgrad3x3d (LDS-DMA; one tile / ragged channel tails / several n tiles)
+    # stride 2 forward on conv3x3d (persistent LDS-DMA): one job / 3 chunks, ragged channel block, 2 x 2 tiles / three channel
+    # tiles, the last one 32 wide / 9 jobs (grid not a multiple of 8) / 272 jobs on 256 workgroups (two jobs per workgroup)
+    (1, 16, 64, 16, 32, 3, 2), (2, 32, 128, 48, 96, 3, 2), (2, 32, 64, 32, 288, 3, 2), (9, 16, 64, 32, 128, 3, 2), (34, 64, 128, 32, 64, 3, 2),
+    (2, 32, 64, 128, 192, 3, 2),                                      # ... with the packed kernel copy: two channel tiles, the second half empty
     (2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1),            # LDS-DMA kernel (conv3x3g): ragged tiles / channels, 3 chunks
     (3, 16, 16, 64, 160, 3, 1), (4, 16, 16, 96, 128, 3, 1), (2, 32, 16, 64, 128, 3, 1), (5, 9, 11, 32, 72, 3, 1),   # conv3x3g, two narrow images per tile (odd batch, ragged)
     (2, 32, 32, 128, 256, 3, 1),                                      # LDS-DMA kernel: forward 4 chunks, data gradient 8 chunks
@@ -356,6 +360,17 @@ def test_conv2d_bf16(U, case, monkeypatch):
     torch.cuda.synchronize()
     close(ya.dense().permute(0, 3, 1, 2), y.detach() + add, 1e-2, "bf16 fwd")
     assert float(ya.base[..., Co:].float().min()) == 512.0
+    ne = ops.conv3x3s2_packed_elems(Co, Ci) if (k == 3 and s == 2) else 0
+    if ne:      # the packed kernel copy of the stride-2 forward kernel: same values in the same LDS positions -> the same bits out
+        pk, pk2 = torch.zeros(ne, dtype=torch.bfloat16, device=DEV), torch.zeros(ne, dtype=torch.bfloat16, device=DEV)
+        same2, tr2 = torch.empty_like(wh), torch.empty((Ci, k * k, Co), dtype=torch.bfloat16, device=DEV)
+        ops.cast_weights_batched(ops.make_cast_table([(w32, same2, tr2, Co, k * k, Ci, Ci, Co, pk)], DEV))     # fused cast kernel
+        ops.cast_weights_batched(ops.make_cast_table([(w32, same2, None, Co, k * k, Ci, Ci, Co, pk2)], DEV))   # element-wise one
+        assert torch.equal(same2, wh) and torch.equal(pk, pk2) and float(pk.float().abs().max()) > 0
+        ya2 = ops.Act(torch.full((B, Ho, Wo, Co + 8), 512.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+        ops.conv2d_fwd(g, xa, wh, b.float().to(DEV), ya2, adda, w_packed=pk)
+        torch.cuda.synchronize()
+        assert torch.equal(ya2.base, ya.base)
 
     Np = -(-Co // 8) * 8
     wt = torch.zeros((Ci, k * k, Np), dtype=torch.bfloat16, device=DEV)
@@ -379,7 +394,8 @@ def test_conv2d_bf16(U, case, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (2, 3, 3, 128, 64, 3), (2, 12, 40, 48, 72, 3),
                                   (1, 16, 32, 136, 64, 3),
-                                  (1, 16, 64, 96, 72, 3), (2, 20, 32, 32, 64, 3)])   # LDS-DMA kernel (upconv3x3g): 3 chunks / ragged N, ragged rows
+                                  (1, 16, 64, 96, 72, 3), (2, 20, 32, 32, 64, 3),    # LDS-DMA kernel (upconv3x3g): 3 chunks / ragged N, ragged rows
+                                  (2, 8, 32, 64, 32, 3), (1, 16, 32, 128, 48, 3)])   # data gradient on conv3x3d (input in a concat buffer)
 def test_conv2d_transpose_bf16(U, case):
     ops = U.ops
     B, H, W, Ci, Co, k = case

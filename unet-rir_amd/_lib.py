@@ -16,13 +16,13 @@ c_stream = C.c_void_p
 class CastDesc(C.Structure):
     """unetrir_cast_desc (include/unetrir.h)."""
     _fields_ = [("w", C.c_void_p), ("same", C.c_void_p), ("transposed", C.c_void_p), ("N", C.c_int), ("T", C.c_int), ("C", C.c_int),
-                ("Cp", C.c_int), ("Np", C.c_int), ("reserved", C.c_int)]
+                ("Cp", C.c_int), ("Np", C.c_int), ("reserved", C.c_int), ("packed_s2", C.c_void_p)]
 
 
 class Config(C.Structure):
     """unetrir_config: kernel-selection switches (include/unetrir.h)."""
     _fields_ = [(n, C.c_int) for n in ("conv3x3", "conv3x3g", "conv3x3g_pair", "conv3x3h", "conv3x3s", "conv3x3r", "stem",
-                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d")]
+                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d")]
 
 
 class ConvGeom(C.Structure):
@@ -93,6 +93,11 @@ _SIGS = {
     # ---- bf16-storage variants (same argument lists; pointers are void*) ----
     "unetrir_conv2d_fwd_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int,
                                           c_f32p, C.c_int, c_stream]),
+    "unetrir_conv3x3s2_packed_elems": (C.c_size_t, [C.c_int, C.c_int]),
+    "unetrir_conv2d_fwd_packed_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
+                                                 c_f32p, C.c_int, c_stream]),
+    "unetrir_conv2d_transpose_dgrad_packed_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int,
+                                                             c_f32p, C.c_int, c_stream]),
     "unetrir_conv2d_dgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
                                             C.c_int, c_stream]),
     "unetrir_conv2d_wgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_float,

@@ -24,6 +24,7 @@ unetrir_config load_config() {
     c.wgrad3x3g = env_int("UNETRIR_WGRAD3X3G", 1);
     c.wgrad3x3r = env_int("UNETRIR_WGRAD3X3R", 1);
     c.wgrad3x3d = env_int("UNETRIR_WGRAD3X3D", 1);
+    c.conv3x3d = env_int("UNETRIR_CONV3X3D", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     return c;
 }
@@ -133,7 +134,8 @@ struct BF16 {
 // ---- Conv2D forward: iteration grid = output grid ----
 template <class P>
 int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, const typename P::T* w, const float* bias,
-                  const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s, float* colstat = nullptr) {
+                  const typename P::T* addend, int ldadd, typename P::T* y, int ldy, hipStream_t s, float* colstat = nullptr,
+                  const void* wpk = nullptr) {
     if (g->k == 3 && g->stride == 1) {
         Conv3Args c{};
         c.colstat = colstat;
@@ -142,6 +144,15 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
         c.flip = UNETRIR_ABL(UNETRIR_ABL_HOST(), 256) ? 2 : 0;      // ablation build only: register-staged kernel without its stores
         // narrow images (the 16 x 16 level) would half-fill the 32-column tiles: bf16 has a paired-image tile for them
         if (use_conv3x3(g->k, g->stride, g->H, g->W) || (P::is_bf16 && conv3x3g_pair_applies(c))) return launch_conv3x3(c, P::is_bf16, s);
+    }
+    if constexpr (P::is_bf16) {
+        if (g->k == 3 && g->stride == 2 && !colstat) {      // strided Conv2D / Conv2DTranspose data gradient: persistent LDS-DMA kernel
+            Conv3Args c{};
+            c.in = x; c.ldi = ldx; c.w = w; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = y; c.ldo = ldy;
+            c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cin; c.N = g->Cout;
+            c.wpk = (g->Cin % 64 == 0 && g->Cout % 64 == 0) ? wpk : nullptr;
+            if (conv3x3d_applies(c)) return launch_conv3x3d_bf16(c, s);
+        }
     }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
@@ -364,6 +375,20 @@ int unetrir_conv2d_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, i
                                (hipStream_t)stream);
 }
 
+size_t unetrir_conv3x3s2_packed_elems(int N, int C) {
+    if (N <= 0 || C <= 0 || (N & 63) || (C & 63)) return 0;
+    return (size_t)((N + 127) / 128) * 128 * 9 * C;
+}
+
+int unetrir_conv2d_fwd_packed_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
+                                   const unetrir_bf16* w_packed, const float* bias, const unetrir_bf16* addend, int ldadd,
+                                   unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !w || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout) return UNETRIR_EINVAL;
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
+    return conv_fwd_impl<BF16>(g, (const __bf16*)x, ldx, (const __bf16*)w, bias, (const __bf16*)addend, ldadd, (__bf16*)y, ldy,
+                               (hipStream_t)stream, nullptr, w_packed);
+}
+
 int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
                               const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, unetrir_stream_t stream) {
     if (!geom_ok(g) || !dy || !wt || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin) return UNETRIR_EINVAL;
@@ -423,6 +448,17 @@ int unetrir_conv2d_transpose_fwd_bf16(const unetrir_conv_geom* g, const unetrir_
     const unetrir_conv_geom c = adjoint_geom(g);
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
     return conv_dgrad_impl<BF16>(&c, (const __bf16*)x, ldx, (const __bf16*)wt, bias, nullptr, 0, (__bf16*)y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_conv2d_transpose_dgrad_packed_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* w,
+                                               const unetrir_bf16* w_packed, const unetrir_bf16* addend, int ldadd,
+                                               unetrir_bf16* dx, int lddx, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !dy || !w || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin)
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(&c), (hipStream_t)stream);
+    return conv_fwd_impl<BF16>(&c, (const __bf16*)dy, lddy, (const __bf16*)w, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx, lddx,
+                               (hipStream_t)stream, nullptr, w_packed);
 }
 
 int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* w,

@@ -414,6 +414,7 @@ __global__ __launch_bounds__(256) void cast_both_batched_kernel(const unetrir_ca
     if (!cast_fused_applies(d)) return;
     __bf16* __restrict__ same = (__bf16*)d.same;
     __bf16* __restrict__ wt = (__bf16*)d.transposed;
+    __bf16* __restrict__ pk = d.T == 9 ? (__bf16*)d.packed_s2 : nullptr;      // third copy in conv3x3d's DMA order (include/unetrir.h)
     const int ntx = d.C >> 6, nty = d.N >> 6;
     const int ntiles = ntx * nty * d.T;
     const int lr = threadIdx.x >> 4, lc = (threadIdx.x & 15) * 4;
@@ -430,6 +431,12 @@ __global__ __launch_bounds__(256) void cast_both_batched_kernel(const unetrir_ca
             bf16x4 h;
             h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
             *reinterpret_cast<bf16x4*>(same + off) = h;
+            if (pk) {
+                const int n = n0 + r, c = c0 + lc;
+                const int m = n & 31, rho = (m & 16) | ((m & 8) >> 1) | ((m & 4) << 1) | (m & 3);       // row of the MFMA block that holds channel m
+                const size_t po = ((((size_t)(n >> 7) * (d.C >> 4) + (c >> 4)) * 36 + t * 4 + ((n >> 5) & 3)) * 64 + rho + 32 * ((c >> 3) & 1)) * 8 + (c & 7);
+                *reinterpret_cast<bf16x4*>(pk + po) = h;
+            }
             tile[r][lc + 0] = h[0]; tile[r][lc + 1] = h[1]; tile[r][lc + 2] = h[2]; tile[r][lc + 3] = h[3];
         }
         __syncthreads();
@@ -448,6 +455,18 @@ __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const unetrir
     if (!d.same || cast_fused_applies(d)) return;
     __bf16* o = (__bf16*)d.same;
     const size_t total = (size_t)d.N * d.T * d.Cp;
+    if (d.packed_s2 && d.T == 9 && (d.C & 15) == 0) {     // packed copy for conv3x3d where the fused kernel does not run
+        __bf16* pk = (__bf16*)d.packed_s2;
+        const size_t tot = (size_t)d.N * 9 * d.C;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (size_t)gridDim.x * 256) {
+            const int c = (int)(i % d.C);
+            const size_t nt_ = i / d.C;
+            const int t = (int)(nt_ % 9), n = (int)(nt_ / 9);
+            const int m = n & 31, rho = (m & 16) | ((m & 8) >> 1) | ((m & 4) << 1) | (m & 3);
+            const size_t po = ((((size_t)(n >> 7) * (d.C >> 4) + (c >> 4)) * 36 + t * 4 + ((n >> 5) & 3)) * 64 + rho + 32 * ((c >> 3) & 1)) * 8 + (c & 7);
+            pk[po] = (__bf16)d.w[i];
+        }
+    }
     if (d.C == d.Cp && (total & 7) == 0 && (((uintptr_t)d.w | (uintptr_t)o) & 15) == 0) {     // flat copy, 8 elements per thread
         const size_t n8 = total >> 3;
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {

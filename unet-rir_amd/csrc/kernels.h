@@ -117,6 +117,7 @@ struct Conv3Args {
     void* out; int ldo;
     int B, H, W, C, N;
     int flip;                 // 0: forward (weight tap t at offset t); 1: data gradient (weight tap 8-t at offset t)
+    const void* wpk;          // nullable; conv3x3d only: the packed copy of w (unetrir_conv3x3s2_packed_elems)
     float* colstat;           // nullable; conv3x3g / conv3x3r<4,1> only: [pixel tile][N][2] per-channel (sum, sum of squares) of the
                               // stored output, one row per 16 x 32 pixel tile (row = (img * tiles_y + ty) * tiles_x + tx)
 };
@@ -139,6 +140,8 @@ bool conv3x3_has_colstat(const Conv3Args& a);
 bool conv3x3s_applies(const Conv3Args& a);          // 64 -> 64 channels: strip kernel with the whole 3x3 kernel resident in LDS
 long long conv3x3s_colstat_rows(const Conv3Args& a);
 int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
+bool conv3x3d_applies(const Conv3Args& a);          // 3x3 stride 2, forward form (H, W = input size): persistent LDS-DMA kernel
+int launch_conv3x3d_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3h_applies(const Conv3Args& a);
 int launch_conv3x3h_bf16(const Conv3Args& a, hipStream_t s);
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s);

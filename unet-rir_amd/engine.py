@@ -276,7 +276,7 @@ class UNetEngine:
         self.theta_t = share.theta_t if share is not None else torch.zeros(max(toff, 4), dtype=torch.float32, device=dev)
         self.pt = {n: self.theta_t[o:o + self.specs[n].numel] for n, o in self.tspec.items()}
         # bf16 mode: bf16 work copies of every trunk kernel in both orientations (the information-vector branch stays fp32)
-        self.ph, self.pth = {}, {}
+        self.ph, self.pth, self.ppk = {}, {}, {}
         if self.dtype == "bf16":
             hoff, hspec = 0, []
             for n, s_ in self.specs.items():
@@ -288,6 +288,15 @@ class UNetEngine:
                 k_ = self.specs[n].numel
                 self.ph[n] = self.theta_h[o:o + k_]
                 self.pth[n] = self.theta_th[o:o + k_]
+            # stride-2 3x3 kernels: a third copy in the order the stride-2 forward kernel's LDS-DMA reads it (csrc/conv3x3d.hip)
+            self.ppk = share.ppk if share is not None else {}
+            for n, _ in hspec if share is None else ():
+                s_ = self.specs[n]
+                strided = n.endswith(".up.kernel") or (n.endswith(".down.kernel") and not n.startswith("enc1."))
+                if strided and s_.shape[1] == 3:
+                    ne = ops.conv3x3s2_packed_elems(s_.shape[0], s_.shape[3])
+                    if ne:
+                        self.ppk[n] = torch.zeros(ne, dtype=torch.bfloat16, device=dev)
         # BatchNorm moving statistics (non-trainable)
         self.bn_names = [n[:-len(".gamma")] for n in self.specs if n.endswith(".gamma")]
         self.moving = share.moving if share is not None else {}
@@ -484,7 +493,7 @@ class UNetEngine:
                 for n in self.ph:
                     s_ = self.specs[n]
                     N, T, C_ = s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3]
-                    ent.append((self.p[n], self.ph[n], self.pth[n], N, T, C_, C_, N))
+                    ent.append((self.p[n], self.ph[n], self.pth[n], N, T, C_, C_, N, self.ppk.get(n)))
                 self._cast_table = ops.make_cast_table(ent, self.device)
             ops.cast_weights_batched(self._cast_table)
         self.t_dirty = False
@@ -593,7 +602,8 @@ class UNetEngine:
         ops.nchw_to_nhwc_pad(spec, self.x4)
         prev = self.x4
         for l in range(1, self.L + 1):
-            ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, self.wf(f"enc{l}.down.kernel"), p[f"enc{l}.down.bias"], self.down[l])
+            ops.conv2d_fwd(self.geo[f"enc{l}.down"], prev, self.wf(f"enc{l}.down.kernel"), p[f"enc{l}.down.bias"], self.down[l],
+                           w_packed=self.ppk.get(f"enc{l}.down.kernel"))
             self._conv_bn_relu_fwd(f"enc{l}.cb1", self.down[l], self.y[l], self.a[l])
             prev = self.a[l]
         if self.wg_stream is None:
@@ -724,7 +734,8 @@ class UNetEngine:
             if not up_bias_done:
                 with self._wg() as ws_:
                     ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
-            ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, self.wf(f"dec{l}.up.kernel"), g_in)
+            ops.conv2d_transpose_dgrad(self.geo[f"dec{l}.up"], g_up, self.wf(f"dec{l}.up.kernel"), g_in,
+                                       w_packed=self.ppk.get(f"dec{l}.up.kernel"))
             ready(f"dec{l}.up.bias")            # after the last reader of this group's parameters (fp32: wf() is the master kernel)
         # bottleneck: z = a_L + conv1x1(dropout(dense(embedding))).  Nothing downstream of the information-vector branch feeds the
         # encoder's backward chain (that needs only g_z), so the whole branch runs on the weight-gradient stream when there is one.

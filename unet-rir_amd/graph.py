@@ -47,6 +47,8 @@ class GraphEngine:
         self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
         self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes (zero-padded 2-channel ends)
         self._h_kernels = []                           # kernels of the convolutions that run in bf16 (work copies needed)
+        self._s2_kernels = []                          # 3x3 stride-2 kernels among them
+        self._ppk = {}
         self._share = share
         self._shared = share._shared if share is not None else {"adam_t": 0, "t_dirty": True, "dropout_step": 0}
         self.include_reg = True       # backward adds d/dw of the l2 terms (False: the caller differentiates them itself)
@@ -155,6 +157,9 @@ class GraphEngine:
         g = ops.geom(B, x.a.H, x.a.W, cin, co, k, stride)
         reg = lambda: (2.0 * L2_COEF / self.n_replicas) if (l2 and self.include_reg) else 0.0
 
+        if h16 and k == 3 and stride == 2:
+            self._s2_kernels.append(kname)             # gets a packed copy for the stride-2 forward kernel (csrc/conv3x3d.hip)
+        wpk = lambda: self._ppk.get(kname)
         wf = (lambda: self._ph[kname]) if h16 else (lambda: self._p[kname])       # kernel as stored ([N][T][C])
         wb = (lambda: self._pth[kname]) if h16 else (lambda: self._pt[kname])     # channel roles swapped ([C][T][N])
 
@@ -170,7 +175,7 @@ class GraphEngine:
             elif transpose:
                 ops.conv2d_transpose_fwd(g, x.a, wb(), self._p[bname], y.a)
             else:
-                ops.conv2d_fwd(g, x.a, wf(), self._p[bname], y.a)
+                ops.conv2d_fwd(g, x.a, wf(), self._p[bname], y.a, w_packed=wpk())
 
         def bwd():
             if transpose:
@@ -182,7 +187,7 @@ class GraphEngine:
             if dense:
                 self._emit(x, dense_dgrad)
             elif transpose:
-                self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, wf(), dst, addend=add))
+                self._emit(x, lambda dst, add: ops.conv2d_transpose_dgrad(g, y.g, wf(), dst, addend=add, w_packed=wpk()))
             else:
                 self._emit(x, lambda dst, add: ops.conv2d_dgrad(g, y.g, wb(), dst, addend=add))
         self._push(fwd, bwd)
@@ -394,6 +399,13 @@ class GraphEngine:
                 k_ = self.specs[n].numel
                 self._ph[n], self._pth[n] = self.theta_h[o:o + k_], self.theta_th[o:o + k_]
                 o += -(-k_ // ALIGN) * ALIGN
+            if sh is not None:
+                self._ppk = sh._ppk
+            else:
+                for n in self._s2_kernels:
+                    ne = ops.conv3x3s2_packed_elems(self.specs[n].shape[0], self.specs[n].shape[3])
+                    if ne:
+                        self._ppk[n] = torch.zeros(ne, dtype=torch.bfloat16, device=dev)
 
     def refresh_transposed(self):
         for n in self._tnames:
@@ -407,7 +419,7 @@ class GraphEngine:
                 for n in self._ph:
                     s_ = self.specs[n]
                     N, T, C_ = s_.shape[0], s_.shape[1] * s_.shape[2], s_.shape[3]
-                    ent.append((self._p[n], self._ph[n], self._pth[n], N, T, C_, C_, N))
+                    ent.append((self._p[n], self._ph[n], self._pth[n], N, T, C_, C_, N, self._ppk.get(n)))
                 self._cast_table = ops.make_cast_table(ent, self.device)
             ops.cast_weights_batched(self._cast_table)
 

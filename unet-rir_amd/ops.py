@@ -88,8 +88,19 @@ class Workspace:
 
 # ---- Conv2D / Conv2DTranspose --------------------------------------------------------------
 
-def conv2d_fwd(g, x: Act, w, bias, y: Act, addend: Act = None):
-    """Conv2D(padding='same') forward (dl_models/u_net.py:269-276, :366, :248, :262)."""
+def conv3x3s2_packed_elems(N, C_):
+    """Elements of the packed copy the stride-2 3x3 forward kernel reads (0: none defined for these channel counts)."""
+    return int(_lib.lib().unetrir_conv3x3s2_packed_elems(int(N), int(C_)))
+
+
+def conv2d_fwd(g, x: Act, w, bias, y: Act, addend: Act = None, w_packed=None):
+    """Conv2D(padding='same') forward (dl_models/u_net.py:269-276, :366, :248, :262).  w_packed: the packed copy of a 3x3
+    stride-2 kernel (bf16 storage; made by cast_weights_batched), passed beside the plain one."""
+    if w_packed is not None:
+        check(_lib.lib().unetrir_conv2d_fwd_packed_bf16(C.byref(g), _p(x), x.ld, _p(w), _p(w_packed), _p(bias), _p(addend),
+                                                        addend.ld if addend is not None else 0, _p(y), y.ld, _stream()),
+              "conv2d_fwd_packed")
+        return
     check(_fn("conv2d_fwd", x.sfx)(C.byref(g), _p(x), x.ld, _p(w), _p(bias), _p(addend),
                                             addend.ld if addend is not None else 0, _p(y), y.ld, _stream()),
           "conv2d_fwd")
@@ -148,7 +159,12 @@ def conv2d_transpose_fwd(g, x: Act, wt, bias, y: Act):
                                                       _stream()), "conv2d_transpose_fwd")
 
 
-def conv2d_transpose_dgrad(g, dy: Act, w, dx: Act, addend: Act = None):
+def conv2d_transpose_dgrad(g, dy: Act, w, dx: Act, addend: Act = None, w_packed=None):
+    if w_packed is not None:
+        check(_lib.lib().unetrir_conv2d_transpose_dgrad_packed_bf16(C.byref(g), _p(dy), dy.ld, _p(w), _p(w_packed), _p(addend),
+                                                                    addend.ld if addend is not None else 0, _p(dx), dx.ld,
+                                                                    _stream()), "conv2d_transpose_dgrad_packed")
+        return
     check(_fn("conv2d_transpose_dgrad", dy.sfx)(C.byref(g), _p(dy), dy.ld, _p(w), _p(addend),
                                                         addend.ld if addend is not None else 0, _p(dx), dx.ld,
                                                         _stream()), "conv2d_transpose_dgrad")
@@ -203,11 +219,15 @@ def transpose_cast_weight_bf16(w, wt, N, T, C_, Np):
 
 def make_cast_table(entries, device):
     """Device-resident unetrir_cast_desc array for cast_weights_batched: entries = [(w fp32 [N][T][C], same bf16 or None,
-    transposed bf16 or None, N, T, C, Cp, Np)].  The returned tensor keeps the table alive; the weight tensors must too."""
+    transposed bf16 or None, N, T, C, Cp, Np[, packed bf16 or None])].  The returned tensor keeps the table alive; the weight
+    tensors must too."""
     arr = (_lib.CastDesc * len(entries))()
-    for i, (w, same, tr, N, T, C_, Cp, Np) in enumerate(entries):
+    for i, ent in enumerate(entries):
+        w, same, tr, N, T, C_, Cp, Np = ent[:8]
+        pk = ent[8] if len(ent) > 8 else None
         arr[i] = _lib.CastDesc(w.data_ptr(), same.data_ptr() if same is not None else None,
-                               tr.data_ptr() if tr is not None else None, N, T, C_, Cp, Np, 0)
+                               tr.data_ptr() if tr is not None else None, N, T, C_, Cp, Np, 0,
+                               pk.data_ptr() if pk is not None else None)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return raw.to(device), len(entries)
 
