@@ -34,6 +34,12 @@ def run(C, N, HW, dt, B=32, K=20):
 
 
 if __name__ == "__main__":
+    for a_ in [v for v in sys.argv[1:] if v.startswith("--")]:       # --conv3x3p=0: kernel-selection switches
+        k_, v_ = a_[2:].split("=")
+        ops.set_config(**{k_: int(v_)})
+    sys.argv = [v for v in sys.argv if not v.startswith("--")]
+    if len(sys.argv) < 2:      # the > 64-channel 3x3 layers of BASELINE configs[1] (forward shape; the data gradient swaps C and N)
+        sys.argv.append("128,128,128;256,128,128;256,256,64;512,256,64;512,512,32;128,64,256;64,64,256")
     if ";" in sys.argv[1] or "," in sys.argv[1]:
         dt = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
         for sh in sys.argv[1].split(";"):

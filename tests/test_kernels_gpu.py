@@ -596,6 +596,57 @@ def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     close(out, dxa.base.double().sum(dim=(0, 1, 2))[c0:], 2e-6, "bias gradient from colstat")
 
 
+@pytest.mark.parametrize("case", [(20, 72, 80, 64, 192), (32, 64, 64, 32, 256), (16, 128, 128, 96, 128)])
+def test_persistent_conv3x3p_equals_conv3x3g_bit_for_bit(U, case):
+    """conv3x3p (persistent: continuous K loop across tiles, direct-store epilogue, per-workgroup statistics) against conv3x3g
+    (one workgroup per tile) on layers with >= 512 tiles: the same MFMA sequence per output, so the stored tensors are
+    IDENTICAL - forward and data gradient, with bias / addend, ragged rows / columns / channel tiles - and the fused
+    column statistics add up to the same totals.  (conv3x3g itself is pinned to the oracle by the cases above and by the
+    full-size window tests, which run through conv3x3p too.)"""
+    ops = U.ops
+    B, H, W, Ci, Co = case
+    gen = torch.Generator(device=DEV); gen.manual_seed(B * 1000 + H)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    g = ops.geom(B, H, W, Ci, Co, 3, 1)
+    x, add = ops.Act(rnd(B, H, W, Ci)), ops.Act(rnd(B, H, W, Co))
+    w, wt = rnd(Co, 9, Ci), rnd(Ci, 9, Co)
+    bias = (torch.rand(Co, device=DEV, generator=gen) - 0.5)
+    res = {}
+    for p_on in (1, 0):
+        ops.set_config(conv3x3p=p_on)
+        rows_f, rows_d = ops.conv2d_colstat_rows(g, 0, x), ops.conv2d_colstat_rows(g, 1, add)
+        y = ops.Act(torch.full((B, H, W, Co + 8), 3.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+        cs = torch.full((rows_f, Co, 2), 7.0, device=DEV)
+        ops.conv2d_fwd_colstat(g, x, w, bias, y, cs, addend=add)
+        dx = ops.Act(torch.full((B, H, W, Ci), 5.0, dtype=torch.bfloat16, device=DEV))
+        csd = torch.full((rows_d, Ci, 2), 7.0, device=DEV)
+        ops.conv2d_dgrad_colstat(g, y, wt, dx, csd)
+        y2 = ops.Act(torch.empty((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
+        ops.conv2d_fwd(g, x, w, None, y2)
+        torch.cuda.synchronize()
+        res[p_on] = (rows_f, rows_d, y.base.clone(), cs.double().sum(0), dx.base.clone(), csd.double().sum(0), y2.base.clone())
+    ntf, ntd = -(-Co // 128), -(-Ci // 128)
+    assert res[1][0] == 256 // ntf and res[0][0] == B * -(-H // 16) * -(-W // 32)        # the persistent kernel did take the layer
+    assert res[1][1] == (256 // ntd if Ci > 64 else res[1][1])
+    assert torch.equal(res[1][2], res[0][2]) and float(res[1][2][..., Co:].float().min()) == 3.0
+    assert torch.equal(res[1][4], res[0][4]) and torch.equal(res[1][6], res[0][6])
+    yd = res[1][2][..., :Co].double()
+    close(res[1][3][:, 0], yd.sum(dim=(0, 1, 2)), 2e-6, "colstat sum")
+    close(res[1][3][:, 1], (yd * yd).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares")
+    close(res[1][3], res[0][3], 2e-6, "colstat totals, persistent vs per tile")
+    if Ci > 64:
+        close(res[1][5], res[0][5], 2e-6, "data-gradient colstat totals")
+    # run-to-run: bit-identical
+    ops.set_config(conv3x3p=1)
+    y3 = ops.Act(torch.empty((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
+    cs3 = torch.zeros((res[1][0], Co, 2), device=DEV)
+    ops.conv2d_fwd_colstat(g, x, w, None, y3, cs3)
+    cs4 = torch.zeros_like(cs3)
+    ops.conv2d_fwd_colstat(g, x, w, None, y3, cs4)
+    torch.cuda.synchronize()
+    assert torch.equal(y3.base, res[1][6]) and torch.equal(cs3, cs4)
+
+
 def test_cast_weights_batched_bf16(U):
     """The two-launch batched work-copy refresh equals the per-layer calls bit for bit."""
     ops = U.ops

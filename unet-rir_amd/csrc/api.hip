@@ -25,6 +25,7 @@ unetrir_config load_config() {
     c.wgrad3x3r = env_int("UNETRIR_WGRAD3X3R", 1);
     c.wgrad3x3d = env_int("UNETRIR_WGRAD3X3D", 1);
     c.conv3x3d = env_int("UNETRIR_CONV3X3D", 1);
+    c.conv3x3p = env_int("UNETRIR_CONV3X3P", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     return c;
 }
@@ -407,6 +408,7 @@ static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) 
     if (conv3x3g_pair_applies(c)) return conv3x3g_colstat_rows(c);          // two images per tile row
     if (!use_conv3x3(g->k, g->stride, g->H, g->W) || !conv3x3_has_colstat(c)) return 0;
     if (conv3x3s_applies(c)) return conv3x3s_colstat_rows(c);               // one row per persistent workgroup
+    if (unetrir_cfg().conv3x3g && conv3x3p_applies(c)) return conv3x3p_colstat_rows(c);    // one row per group of N / 128 workgroups
     return (long long)g->B * ((g->H + 15) / 16) * ((g->W + 31) / 32);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }

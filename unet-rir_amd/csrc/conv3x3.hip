@@ -270,6 +270,7 @@ int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
     // bf16: the row-reuse kernel (conv3x3r.hip) unless the conv3x3r switch is off or a timing ablation asks for the no-store variant
     const bool rowreuse = unetrir_cfg().conv3x3r != 0, dma = unetrir_cfg().conv3x3g != 0, stem = unetrir_cfg().stem != 0;
     if (bf16 && stem && stem3x3_applies(a)) return launch_stem3x3_bf16(a, s);          // first layer: 8 stored channels -> 64
+    if (bf16 && dma && conv3x3p_applies(a)) return launch_conv3x3p_bf16(a, s);
     if (bf16 && dma && conv3x3g_applies(a)) return launch_conv3x3g_bf16(a, s);
     if (bf16 && conv3x3s_applies(a)) return launch_conv3x3s_bf16(a, s);
     if (bf16 && conv3x3h_applies(a)) return launch_conv3x3h_bf16(a, s);

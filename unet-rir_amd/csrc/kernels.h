@@ -140,6 +140,9 @@ bool conv3x3_has_colstat(const Conv3Args& a);
 bool conv3x3s_applies(const Conv3Args& a);          // 64 -> 64 channels: strip kernel with the whole 3x3 kernel resident in LDS
 long long conv3x3s_colstat_rows(const Conv3Args& a);
 int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
+bool conv3x3p_applies(const Conv3Args& a);          // conv3x3g's layers with >= 512 tiles: persistent form, continuous K loop across tiles
+long long conv3x3p_colstat_rows(const Conv3Args& a);
+int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3d_applies(const Conv3Args& a);          // 3x3 stride 2, forward form (H, W = input size): persistent LDS-DMA kernel
 int launch_conv3x3d_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3h_applies(const Conv3Args& a);
