@@ -50,7 +50,8 @@ constexpr uint32_t OOB = 0xF0000000u;
 struct Tile { int img, y0, x0, n0; };
 }  // namespace
 
-__global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd) {
+// abl (ablation build only): 1 no patch DMA, 8 no kernel DMA (after the prologue), 2 no output stores, 4 no MFMA loop
+__global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd, int abl) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[PSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
 
     // (the per-lane offsets of a tile's patch are recomputed at every issue: 5 x 6 vector instructions per chunk against
     //  10 registers held through the K loop - the loop sits at the register limit)
+    bool started = false;
     auto issue_p = [&](const __amdgpu_buffer_rsrc_t& rs, const Tile& t, int ch, int buf) {
+        if (UNETRIR_ABL(abl, 1) && started) return;
         unsigned char* dst = smem + buf * PP_BYTES;
         const int base = (((t.y0 - 1) * a.W + t.x0 - 1) * a.ldi) * 2 + ch * 64;
 #pragma unroll
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
         }
     };
     auto issue_w = [&](int ch, int dx, int buf) {
+        if (UNETRIR_ABL(abl, 8) && started) return;
         unsigned char* dst = smem + 2 * PP_BYTES + buf * PW_BYTES;
         const uint32_t off = ch * 64 + dx * dxs;
 #pragma unroll
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        started = true;
 
         int pbuf = 0;                                     // patch buffer of the current chunk
         int nst_prev = 0;                                 // output stores issued by this wave just before the current step
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                          \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) MMA16(acc[r - dy][h][t], wf[dy][t], pf[r][h]); \
     }
+                    if (!UNETRIR_ABL(abl, 4)) {
                     RDW(0); RDP(0); RDW(1); RDP(1); RDW(2); RDP(2);          // 18 reads in flight
                     __builtin_amdgcn_s_setprio(1);
                     LGKM_WAIT(12); ROWS16(0);
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
                     LGKM_WAIT(2); ROWS16(4);
                     LGKM_WAIT(0); ROWS16(5);
                     __builtin_amdgcn_s_setprio(0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #undef RDW
 #undef RDP
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
                         bf16x8 ov;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) ov[e] = (__bf16)v[e];
-                        if (ok) {
+                        if (ok && !UNETRIR_ABL(abl, 2)) {
                             if (a.colstat) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) { const float s = (float)ov[e]; cs_s[m][e] += s; cs_q[m][e] += s * s; }
@@ -347,6 +354,6 @@ long long conv3x3p_colstat_rows(const Conv3Args& a) { return 256 / ((a.N + PBN -
 int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s) {
     const long long pt = pixel_tiles(a);
     const int per_xcd = (int)((pt + 7) / 8);
-    hipLaunchKernelGGL(conv3x3p_bf16_kernel, dim3(256), dim3(512), 0, s, a, (int)pt, per_xcd);
+    hipLaunchKernelGGL(conv3x3p_bf16_kernel, dim3(256), dim3(512), 0, s, a, (int)pt, per_xcd, UNETRIR_ABL_HOST());
     return (int)hipGetLastError();
 }
