@@ -33,6 +33,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), accv, 0, 0, 0)
 
 namespace {
+// sum over the 16 lanes of a DPP row, every lane gets the total: the xor-butterfly order (1, 2, 4, 8) on single vector
+// instructions (quad permutes, then the mirrored half / whole row: after two steps the lanes of a quad hold the same value)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    return dpp_add<0x140>(v);  // row_mirror
+}
 constexpr int PPC = 34;                     // patch columns
 constexpr int PTR = 16;                     // tile rows
 constexpr int PNPX = (PTR + 2) * PPC;       // 612 patch pixels
@@ -261,6 +272,33 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { cs_s[m][e] = 0.f; cs_q[m][e] = 0.f; }
+            // interior tiles without an addend (all but the image's ragged edges): no lane masks, one buffer store per (row, half, m)
+            // with the tile-constant part of the address in a scalar register
+            const bool fast = !addend && cur.y0 + PTR <= a.H && cur.x0 + 32 <= a.W && n0 + PBN <= a.N;
+            if (fast) {
+                const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(out + (size_t)cur.img * a.H * a.W * a.ldo), (short)0, (int)((((size_t)a.H * a.W - 1) * a.ldo + a.N) * 2), 0x00020000);
+                const int voff = (((cur.y0 + 4 * wm) * a.W + cur.x0 + l15) * a.ldo + nb) * 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int soff = ((i * a.W + 16 * h) * a.ldo) * 2;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            bf16x8 ov;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) ov[e] = (__bf16)(acc[i][h][2 * m + (e >> 2)][e & 3] + bias_[m][e]);
+                            if (a.colstat) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { const float s_ = (float)ov[e]; cs_s[m][e] += s_; cs_q[m][e] += s_ * s_; }
+                            }
+                            if (!UNETRIR_ABL(abl, 2))
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_out, voff + 64 * m, soff, 0);
+                        }
+                    }
+                nst = 16;
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int y = cur.y0 + 4 * wm + i;
@@ -303,11 +341,7 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-#pragma unroll
-                        for (int off = 1; off < 16; off <<= 1) {
-                            cs_s[m][e] += __shfl_xor(cs_s[m][e], off);
-                            cs_q[m][e] += __shfl_xor(cs_q[m][e], off);
-                        }
+                    { cs_s[m][e] = row_sum16(cs_s[m][e]); cs_q[m][e] = row_sum16(cs_q[m][e]); }
                 if (l15 == 0) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
