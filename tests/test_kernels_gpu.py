@@ -647,6 +647,35 @@ def test_persistent_conv3x3p_equals_conv3x3g_bit_for_bit(U, case):
     assert torch.equal(y3.base, res[1][6]) and torch.equal(cs3, cs4)
 
 
+@pytest.mark.parametrize("case", [(20, 40, 72, 64, 128), (32, 32, 32, 96, 256), (8, 128, 128, 128, 64)])
+def test_persistent_upconv3x3q_equals_upconv3x3g_bit_for_bit(U, case):
+    """upconv3x3q (persistent) against upconv3x3g (one workgroup per tile) on layers with >= 512 tiles - Conv2DTranspose forward
+    (bias, output into a concat buffer) and the strided convolution's data gradient accumulating in place (addend == out): the
+    same MFMA sequence per output, so the tensors are identical; ragged coarse rows / columns, two-chunk K loop."""
+    ops = U.ops
+    B, H, W, Ci, Co = case                 # coarse H x W with Ci channels -> 2H x 2W with Co channels
+    gen = torch.Generator(device=DEV); gen.manual_seed(B * 1000 + H)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    x = ops.Act(rnd(B, H, W, Ci))
+    wt = rnd(Co, 9, Ci)                    # [out channel][tap][in channel]: the orientation both call sites pass
+    bias = (torch.rand(Co, device=DEV, generator=gen) - 0.5)
+    skip = rnd(B, 2 * H, 2 * W, Co)
+    gt = ops.geom(B, H, W, Ci, Co, 3, 2)                     # Conv2DTranspose: coarse in, fine out
+    gs = ops.geom(B, 2 * H, 2 * W, Co, Ci, 3, 2)             # strided Conv2D (fine Co -> coarse Ci): its data gradient is the same kernel
+    res = {}
+    for q_on in (1, 0):
+        ops.set_config(upconv3x3q=q_on)
+        y = ops.Act(torch.full((B, 2 * H, 2 * W, 2 * Co), 3.0, dtype=torch.bfloat16, device=DEV), Co, Co)
+        ops.conv2d_transpose_fwd(gt, x, wt, bias, y)
+        acc = ops.Act(skip.clone())
+        ops.conv2d_dgrad(gs, x, wt, acc, addend=acc)
+        torch.cuda.synchronize()
+        res[q_on] = (y.base.clone(), acc.base.clone())
+    assert torch.equal(res[1][0], res[0][0]) and float(res[1][0][..., :Co].float().min()) == 3.0
+    assert torch.equal(res[1][1], res[0][1])
+    assert float((res[1][1].float() - skip.float()).abs().max()) > 0.5          # the accumulation did happen
+
+
 def test_cast_weights_batched_bf16(U):
     """The two-launch batched work-copy refresh equals the per-layer calls bit for bit."""
     ops = U.ops

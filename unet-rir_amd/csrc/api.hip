@@ -26,6 +26,7 @@ unetrir_config load_config() {
     c.wgrad3x3d = env_int("UNETRIR_WGRAD3X3D", 1);
     c.conv3x3d = env_int("UNETRIR_CONV3X3D", 1);
     c.conv3x3p = env_int("UNETRIR_CONV3X3P", 1);
+    c.upconv3x3q = env_int("UNETRIR_UPCONV3X3Q", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     return c;
 }

@@ -130,6 +130,8 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
 bool head_dgrad_mfma_applies(int W, int C);
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s);
 bool upconv3x3g_applies(const Conv3Args& a);
+bool upconv3x3q_applies(const Conv3Args& a);        // upconv3x3g's layers with >= 512 tiles: persistent form
+int launch_upconv3x3q_bf16(const Conv3Args& a, hipStream_t s);
 int launch_upconv3x3g_bf16(const Conv3Args& a, hipStream_t s);
 bool conv3x3g_applies(const Conv3Args& a);
 bool conv3x3g_pair_applies(const Conv3Args& a);     // images <= 16 pixels wide: two images per tile

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(512) void upconv3x3_kernel(const Conv3Args a) {
 
 int launch_upconv3x3(const Conv3Args& a, int bf16, hipStream_t s) {
     const long long tiles = (long long)a.B * ((a.H + UR - 1) / UR) * ((a.W + UC - 1) / UC) * ((a.N + UBN - 1) / UBN);
+    if (bf16 && upconv3x3q_applies(a)) return launch_upconv3x3q_bf16(a, s);
     if (bf16 && upconv3x3g_applies(a)) return launch_upconv3x3g_bf16(a, s);
     if (bf16) hipLaunchKernelGGL((upconv3x3_kernel<__bf16, true>), dim3((unsigned)tiles), dim3(512), 0, s, a);
     else hipLaunchKernelGGL(upconv3x3_kernel<float>, dim3((unsigned)tiles), dim3(512), 0, s, a);
