@@ -1,4 +1,5 @@
-"""wgrad3x3g with / without the XCD remap (ablation build, bit 512): python scripts/abl_wgrad.py "128,128,128;256,256,64;128,64,256" """
+"""wgrad3x3g timing ablations (ablation build; bits: 512 no XCD remap, 1 no DMA after the first patch, 2 no partial stores,
+4 no MFMA): python scripts/abl_wgrad.py "128,128,128;256,256,64;128,64,256" [modes, default 0,512] """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +19,7 @@ for sh in sys.argv[1].split(";"):
     g = ops.geom(B, HW, HW, Cc, N, 3, 1)
     ws = ops.Workspace(dev)
     for rnd in range(3):
-        for m in (0, 512):
+        for m in ([int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 512)):
             aset(m)
             for _ in range(3): ops.conv2d_wgrad(g, x, dy, dw, ws)
             torch.cuda.synchronize()
@@ -27,5 +28,5 @@ for sh in sys.argv[1].split(";"):
             for _ in range(20): ops.conv2d_wgrad(g, x, dy, dw, ws)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
-            print(f"C={Cc} N={N} {HW}: remap={'off' if m else 'on '} {ms*1e3:7.1f} us {2.0*B*HW*HW*Cc*N*9/ms/1e9:6.0f} TF/s", flush=True)
+            print(f"C={Cc} N={N} {HW}: abl={m:3d} {ms*1e3:7.1f} us {2.0*B*HW*HW*Cc*N*9/ms/1e9:6.0f} TF/s", flush=True)
 aset(0)

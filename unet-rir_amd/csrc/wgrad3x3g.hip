@@ -44,8 +44,10 @@ __device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
 // raw barrier is workgroup wide) and at the end the second quartet hands its 144 accumulators per lane to the first through
 // the then idle 160 KB of LDS.  Same occupancy, half as many partial slabs: half the fp32 partial traffic and half the
 // split-K reduction (75 MB written + read per launch with NH = 1).
+struct WgSrc { __amdgpu_buffer_rsrc_t rx, rd; int iy0, ix0, py0, px0, xbase, dbase, gv; };     // DMA sources of one patch
+
 template <int NH>
-__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a) {
+__global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a, int abl) {   // abl (ablation build only): 1 no DMA after the first patch, 2 no partial stores, 4 no MFMA
     __shared__ __attribute__((aligned(1024))) unsigned char smem_all[NH * 2 * WBUF];
     const int half = NH == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
     unsigned char* smem = smem_all + half * 2 * WBUF;
@@ -108,34 +110,40 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
     const size_t x_img = (size_t)a.IH * a.IW * a.ldx, d_img = (size_t)a.OH * a.OW * a.lddy;
     const int x_rec = (int)((((size_t)a.IH * a.IW - 1) * a.ldx + a.C) * 2), d_rec = (int)((((size_t)a.OH * a.OW - 1) * a.lddy + a.N) * 2);
 
-    auto issue = [&](int g, int buf) {
-        const bool gv = g < G;
-        if (!gv) g = G - 1;
+    // A patch's DMA is 10 wave-instructions (6 x, 4 dy).  Issuing them back to back at the top of a patch costs the wave
+    // 60-180 cycles each with the matrix pipe idle (both waves of a SIMD run the same program): measured, DMA and MFMA time
+    // ADDED UP (154 us = 111 without DMA + 43).  They are issued two at a time between the K steps of the patch instead.
+    bool started = false;
+    auto patch_src = [&](int g) {
+        WgSrc q;
+        q.gv = g < G;
+        if (!q.gv) g = G - 1;
         const int img = g / per_img;
         const int rem = g - img * per_img;
         const int pyi = rem / a.npx, pxi = rem - pyi * a.npx;
-        const int py0 = pyi * WTPH, px0 = pxi * WTPW;
-        const int iy0 = py0 - a.pad_t, ix0 = px0 - a.pad_l;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + img * x_img), (short)0, x_rec, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + img * d_img), (short)0, d_rec, 0x00020000);
+        q.py0 = pyi * WTPH; q.px0 = pxi * WTPW;
+        q.iy0 = q.py0 - a.pad_t; q.ix0 = q.px0 - a.pad_l;
+        q.rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + img * x_img), (short)0, x_rec, 0x00020000);
+        q.rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + img * d_img), (short)0, d_rec, 0x00020000);
+        q.xbase = ((q.iy0 * a.IW + q.ix0) * a.ldx + c0) * 2;       // may be negative; only used for valid pixels
+        q.dbase = ((q.py0 * a.OW + q.px0) * a.lddy + n0) * 2;
+        return q;
+    };
+    auto piece = [&](const WgSrc& q, int buf, int j) {             // j = 0..5: x instruction j, 6..9: dy instruction j - 6 (compile-time)
+        if (UNETRIR_ABL(abl, 1) && started) return;
         unsigned char* xb = smem + buf * WBUF;
-        unsigned char* db = xb + WX_BYTES;
-        const int xbase = ((iy0 * a.IW + ix0) * a.ldx + c0) * 2;       // may be negative; only used for valid pixels
-        const int dbase = ((py0 * a.OW + px0) * a.lddy + n0) * 2;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        if (j < 6) {
             int i = wave + 4 * j;
             if (i > WX_INSTR - 1) i = WX_INSTR - 1;
-            const int iy = iy0 + xpr[j], ix = ix0 + xpc[j];
-            const bool ok = gv && xcok[j] && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-            const uint32_t off = ok ? (uint32_t)(xbase + (int)xrel[j]) : WOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(xb + i * 1024), 16, off, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = gv && dnok[j] && (py0 + dr_[j]) < a.OH && (px0 + dc_[j]) < a.OW;
-            const uint32_t off = ok ? (uint32_t)(dbase + (int)drel[j]) : WOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lptr_t)(db + (wave + 4 * j) * 1024), 16, off, 0, 0, 0);
+            const int iy = q.iy0 + xpr[j < 6 ? j : 0], ix = q.ix0 + xpc[j < 6 ? j : 0];
+            const bool ok = q.gv && xcok[j < 6 ? j : 0] && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+            const uint32_t off = ok ? (uint32_t)(q.xbase + (int)xrel[j < 6 ? j : 0]) : WOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q.rx, (lptr_t)(xb + i * 1024), 16, off, 0, 0, 0);
+        } else {
+            const int jj = j >= 6 ? j - 6 : 0;
+            const bool ok = q.gv && dnok[jj] && (q.py0 + dr_[jj]) < a.OH && (q.px0 + dc_[jj]) < a.OW;
+            const uint32_t off = ok ? (uint32_t)(q.dbase + (int)drel[jj]) : WOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(q.rd, (lptr_t)(xb + WX_BYTES + (wave + 4 * jj) * 1024), 16, off, 0, 0, 0);
         }
     };
 
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
 #define RDX(lo, hi, R, KW) do { TRR(lo, xa[(KW) & 3], (R) * (WXW * 128) + (KW) * 128); \
                                 TRR(hi, xa[((KW) + 4) & 3], (R) * (WXW * 128) + ((KW) + 4) * 128); } while (0)
 #define RDD(lo, hi, R) do { TRR(lo, da, (R) * (WTPW * 128)); TRR(hi, da, (R) * (WTPW * 128) + 4 * 128); } while (0)
-#define MM(T_, A_, B_) acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[T_], 0, 0, 0)
+#define MM(T_, A_, B_) do { if (!UNETRIR_ABL(abl, 4)) acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[T_], 0, 0, 0); } while (0)
     // one K step: dy row R against x rows R (kh 0), R+1, R+2.  S0 = ring slot of x row R (refilled with row R+3 once the
     // kh = 0 products are issued), S1, S2 = slots of rows R+1, R+2.
 #define STEP(R, S0, S1, S2, DC_LO, DC_HI, DN_LO, DN_HI, MORE)                                                     \
@@ -178,13 +186,21 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         MM(6, fd, frag(xl[S2][0], xh[S2][0])); MM(7, fd, frag(xl[S2][1], xh[S2][1])); MM(8, fd, frag(xl[S2][2], xh[S2][2])); \
     } while (0)
 
-    if (n_it > 0) issue(g0, 0);
+    if (n_it > 0) {
+        const WgSrc s0 = patch_src(g0);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) piece(s0, 0, j);
+    }
+    started = true;
     int k = 0;
     for (int it = 0; it < n_it; ++it, k ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of patch g has landed ...
         __builtin_amdgcn_s_barrier();                            // ... everybody's has; everybody is done reading the other buffer
         asm volatile("" ::: "memory");
-        if (it + 1 < n_it) issue(g0 + it + 1, k ^ 1);
+        const bool nxt_on = it + 1 < n_it;
+        const WgSrc nx = patch_src(nxt_on ? g0 + it + 1 : g0 + it);
+        const int nb_ = k ^ 1;
+#define PIECES(J0, J1) do { if (nxt_on) { piece(nx, nb_, J0); piece(nx, nb_, J1); } } while (0)
         const uint32_t xb = lds0 + k * WBUF, db = xb + WX_BYTES;
         uint32_t xa[4];
 #pragma unroll
@@ -195,17 +211,18 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         RDX(xl[1][0], xh[1][0], 1, 0); RDX(xl[1][1], xh[1][1], 1, 1); RDX(xl[1][2], xh[1][2], 1, 2);
         RDX(xl[2][0], xh[2][0], 2, 0); RDX(xl[2][1], xh[2][1], 2, 1); RDX(xl[2][2], xh[2][2], 2, 2);
         RDD(d0l, d0h, 0);
-        STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true);
-        STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true);
-        STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true);
-        STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true);
-        STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true);
+        STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true); PIECES(0, 1);
+        STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true); PIECES(2, 3);
+        STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true); PIECES(4, 5);
+        STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true); PIECES(6, 7);
+        STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true); PIECES(8, 9);
         STEP(5, 2, 0, 1, d1l, d1h, d0l, d0h, true);
         STEP(6, 0, 1, 2, d0l, d0h, d1l, d1h, true);
         // last step: x row 10 does not exist; nothing left to prefetch
         STEP(7, 1, 2, 0, d1l, d1h, d0l, d0h, false);
     }
 #undef STEP
+#undef PIECES
 #undef MM
 #undef RDD
 #undef RDX
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
     }
     float* part = a.part + (size_t)split_id * a.N * 9 * a.C;
     const int c = c0 + wc * 32 + (lane & 31);
-    if (c < a.C) {
+    if (c < a.C && !UNETRIR_ABL(abl, 2)) {
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -270,8 +287,8 @@ int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, v
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
     a.xcd_remap = (tiles > 1 && ns % 8 == 0 && !UNETRIR_ABL(UNETRIR_ABL_HOST(), 512)) ? 1 : 0;
-    if (nh == 2) hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<2>, dim3(tiles, ns), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<1>, dim3(tiles, ns), dim3(256), 0, s, a);
+    if (nh == 2) hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<2>, dim3(tiles, ns), dim3(512), 0, s, a, UNETRIR_ABL_HOST());
+    else hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<1>, dim3(tiles, ns), dim3(256), 0, s, a, UNETRIR_ABL_HOST());
     const int err = (int)hipGetLastError();
     if (err || direct) return err;
     return launch_splitk_reduce((const float*)ws, ns, nout, dw, reg, w, s);
