@@ -247,7 +247,7 @@ def roofline_block(main, sub, dtype):
         "traffic": traffic(dtype)[0], "traffic_note": traffic(dtype)[1],
         "kernel": ("igemm_fwd_kernel / conv3x3_kernel / wgrad3x3_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit-GEMM conv: fwd, dgrad, wgrad)"
                    if dtype == "f32" else
-                   "conv3x3g / conv3x3h / upconv3x3g / igemm_fwd_bf16 (fwd, dgrad) + wgrad3x3g / wgrad3x3_bf16 (wgrad): bf16 "
+                   "conv3x3p / conv3x3g / conv3x3s / conv3x3h / upconv3x3q / conv3x3d (fwd, dgrad) + wgrad3x3g / wgrad3x3d (wgrad): bf16 "
                    "v_mfma_f32_16x16x32_bf16 / 32x32x16 convolutions, fp32 accumulate") + "; layers with Cin,Cout > 8",
         "measured_on": ("forward conv launches of the timed region (backward brackets overlap: wgrad runs on a side stream)"
                         if overlap else "all conv launches (fwd, dgrad, wgrad) of the timed region"),

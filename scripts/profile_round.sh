@@ -17,5 +17,6 @@ for d in stats_ss stats_ov; do python3 scripts/stats_summary.py $OUT/$d/s_kernel
 python3 scripts/pmc_summary.py $OUT/pmc_fetch/p_counter_collection.csv > $OUT/${TAG}_bf16_pmc_fetch_size.txt
 python3 scripts/pmc_summary.py $OUT/pmc_write/p_counter_collection.csv > $OUT/${TAG}_bf16_pmc_write_size.txt
 python3 scripts/pmc_mfma.py $OUT/pmc_mfma/p_counter_collection.csv > $OUT/${TAG}_bf16_pmc_mfma_busy.txt
+python3 scripts/pmc_traffic.py $OUT/${TAG}_bf16_pmc_fetch_size.txt $OUT/${TAG}_bf16_pmc_write_size.txt conv3x3p_bf16_kernel $TAG > $OUT/pmc_traffic.json
 rm -rf $OUT/stats_ss $OUT/stats_ov $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma
 ls -la $OUT
