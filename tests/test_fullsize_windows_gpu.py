@@ -156,8 +156,8 @@ def test_conv3x3_forward_and_data_gradient_windows(U, Ci, Co, HW, ld):
 
 @pytest.mark.parametrize("Ci,Co,HW", [(64, 128, 256), (128, 256, 128)])
 def test_strided_conv_windows(U, Ci, Co, HW):
-    """enc2.down / enc3.down (dl_models/u_net.py:269-276): forward (tap-table implicit GEMM), data gradient with the in-place
-    skip-gradient addend (upconv3x3g)."""
+    """enc2.down / enc3.down (dl_models/u_net.py:269-276): forward (conv3x3d, plain and packed kernel copy), data gradient with the
+    in-place skip-gradient addend (upconv3x3q)."""
     ops = U.ops
     g = ops.geom(B, HW, HW, Ci, Co, 3, 2)
     Ho = HW // 2
@@ -166,6 +166,15 @@ def test_strided_conv_windows(U, Ci, Co, HW):
     bias = (torch.rand(Co, device=DEV) - 0.5)
     y = ops.Act(torch.empty((B, Ho, Ho, Co), dtype=torch.bfloat16, device=DEV))
     ops.conv2d_fwd(g, x, wh, bias, y)
+    ne = ops.conv3x3s2_packed_elems(Co, Ci)
+    if ne:            # the packed kernel copy the engines pass to the stride-2 forward kernel: the same bits out
+        pk = torch.zeros(ne, dtype=torch.bfloat16, device=DEV)
+        ops.cast_weights_batched(ops.make_cast_table([(w32, torch.empty_like(wh), torch.empty_like(wt), Co, 9, Ci, Ci, Co, pk)], DEV))
+        yp = ops.Act(torch.empty((B, Ho, Ho, Co), dtype=torch.bfloat16, device=DEV))
+        ops.conv2d_fwd(g, x, wh, bias, yp, w_packed=pk)
+        torch.cuda.synchronize()
+        assert torch.equal(yp.base, y.base)
+        del yp, pk
     gy = ops.Act(_rand_bf16((B, Ho, Ho, Co), 23))
     skip0 = _rand_bf16((B, HW, HW, 2 * Ci), 24)                        # g_cat: the skip half accumulates in place
     skip = ops.Act(skip0.clone(), 0, Ci)
@@ -194,8 +203,8 @@ def test_strided_conv_windows(U, Ci, Co, HW):
 
 @pytest.mark.parametrize("Ci,Co,hw", [(128, 64, 128), (256, 128, 64)])
 def test_conv_transpose_windows(U, Ci, Co, hw):
-    """dec1.up / dec2.up (dl_models/u_net.py:297-304): forward into the upper half of the concat buffer (upconv3x3g), data
-    gradient (tap-table implicit GEMM on the adjoint geometry)."""
+    """dec1.up / dec2.up (dl_models/u_net.py:297-304): forward into the upper half of the concat buffer (upconv3x3q), data
+    gradient (conv3x3d on the adjoint geometry)."""
     ops = U.ops
     g = ops.geom(B, hw, hw, Ci, Co, 3, 2)
     HW = 2 * hw
