@@ -311,6 +311,11 @@ int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int
  *      unetrir_conv2d_colstat_rows_bf16 returns 0 when the kernel serving this layer (geometry, dgrad flag, pixel stride
  *      ld_in of its input) has no fused statistics; the *_colstat entry points then return UNETRIR_EINVAL. */
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in);
+/* which hand-written kernel serves a 3x3 stride-1 layer (forward or data gradient) under the switches in effect: for tests and
+ * measurement scripts that must know what they are looking at */
+enum { UNETRIR_K3_TAPTABLE = 0, UNETRIR_K3_CONV3X3R = 1, UNETRIR_K3_CONV3X3G = 2, UNETRIR_K3_CONV3X3G_PAIR = 3, UNETRIR_K3_CONV3X3H = 4,
+       UNETRIR_K3_CONV3X3S = 5, UNETRIR_K3_CONV3X3P = 6, UNETRIR_K3_STEM = 7 };
+int unetrir_conv3x3_kernel_id_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in);
 int unetrir_conv2d_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
                                     const float* bias, const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy,
                                     float* colstat, unetrir_stream_t stream);

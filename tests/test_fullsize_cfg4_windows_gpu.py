@@ -43,7 +43,7 @@ def test_cfg4_conv3x3_forward_and_data_gradient_windows(U, Ci, Co, HW, ld):
     ops = U.ops
     g = ops.geom(B4, HW, HW, Ci, Co, 3, 1)
     x = ops.Act(torch.empty((1, 8, 8, ld), dtype=torch.bfloat16, device=DEV), 0, Ci)
-    assert ops.conv2d_colstat_rows(g, 0, x) == 256 // max(Co // 128, 1)          # the persistent kernel serves the layer
+    assert ops.conv3x3_kernel(g, 0, x) == "conv3x3p"                              # the persistent kernel serves the layer
 
 
 def test_cfg4_deep_conv3x3_windows(U, monkeypatch):

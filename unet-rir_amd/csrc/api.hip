@@ -50,7 +50,40 @@ extern "C" int unetrir_set_config(const unetrir_config* in) {
 #ifdef UNETRIR_ABLATIONS
 int g_unetrir_abl = 0;
 extern "C" int unetrir_abl_set(int v) { g_unetrir_abl = v; return 0; }
+// A stand-in for a communication kernel beside the step (ablation build only): n workgroups that hold `lds` bytes of LDS and
+// spin for `cycles` clock cycles - CUs on which a 158 KB persistent workgroup cannot be placed meanwhile.
+__global__ void abl_hog_kernel(long long cycles, int lds, unsigned* sink) {
+    extern __shared__ unsigned hog_smem[];
+    if (lds > 0) hog_smem[threadIdx.x] = threadIdx.x;
+    const long long t0 = wall_clock64();
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < cycles) acc += hog_smem[(threadIdx.x + acc) & 63];
+    if (acc == 0xFFFFFFFFu) *sink = acc;
+}
+extern "C" int unetrir_abl_hog(int n, long long cycles, int lds, void* sink, void* stream) {
+    hipLaunchKernelGGL(abl_hog_kernel, dim3(n), dim3(256), (size_t)lds, (hipStream_t)stream, cycles, lds, (unsigned*)sink);
+    return (int)hipGetLastError();
+}
 #endif
+
+// ---- tile-ticket slots of the persistent kernels (kernels.h): a static device array, one slot per stream in use
+__device__ unsigned g_sched_slots[128][80];
+unsigned* sched_slot(hipStream_t s) {
+    static std::mutex mu;
+    static hipStream_t owner[128];
+    static int used = 0;
+    static unsigned* base = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return nullptr;
+        base = (unsigned*)p;
+    }
+    for (int i = 0; i < used; ++i) if (owner[i] == s) return base + i * 80;
+    if (used == 128) return nullptr;
+    owner[used] = s;
+    return base + (used++) * 80;
+}
 
 namespace {
 
@@ -413,6 +446,22 @@ static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) 
     return (long long)g->B * ((g->H + 15) / 16) * ((g->W + 31) / 32);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }
+
+int unetrir_conv3x3_kernel_id_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) {
+    if (!geom_ok(g) || g->k != 3 || g->stride != 1) return UNETRIR_K3_TAPTABLE;
+    Conv3Args c{};
+    c.B = g->B; c.H = g->H; c.W = g->W; c.ldi = ld_in;
+    c.C = dgrad ? g->Cout : g->Cin; c.N = dgrad ? g->Cin : g->Cout; c.flip = dgrad ? 1 : 0;
+    const bool dma = unetrir_cfg().conv3x3g != 0;
+    if (conv3x3g_pair_applies(c) && dma) return UNETRIR_K3_CONV3X3G_PAIR;
+    if (!use_conv3x3(g->k, g->stride, g->H, g->W)) return UNETRIR_K3_TAPTABLE;
+    if (unetrir_cfg().stem && stem3x3_applies(c)) return UNETRIR_K3_STEM;
+    if (dma && conv3x3p_applies(c)) return UNETRIR_K3_CONV3X3P;
+    if (dma && conv3x3g_applies(c)) return UNETRIR_K3_CONV3X3G;
+    if (conv3x3s_applies(c)) return UNETRIR_K3_CONV3X3S;
+    if (conv3x3h_applies(c)) return UNETRIR_K3_CONV3X3H;
+    return UNETRIR_K3_CONV3X3R;
+}
 
 int unetrir_conv2d_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w, const float* bias,
                                     const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy, float* colstat,

@@ -16,7 +16,7 @@
 //     that read the same patch run at the same time on one XCD, and a workgroup keeps ONE channel tile for all its tiles
 //     (its kernel tiles stay hot in L2, and its fused column statistics add up per lane).
 // K loop, LDS images, swizzles, ring and waits are those of conv3x3g.hip (16x16x32 body); see there.  Fused column
-// statistics: one row per group of N / 128 workgroups (a.colstat rows = conv3x3p_colstat_rows).
+// statistics: one row per pixel tile, as conv3x3g writes them (which workgroup serves a tile varies from run to run; the rows do not).
 // Requires C % 32 == 0, N / 128 tiles in {1, 2, 4, 8}, at least 512 tiles; otherwise conv3x3g.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,16 +53,18 @@ constexpr int PBN = 128;
 constexpr int PW_BYTES = 3 * PBN * 64;      // 24576 = 24 wave-instructions: [3 vertical taps][128 channels][32 input channels]
 constexpr int PRP = PPC * 64;               // patch row pitch
 constexpr int PRING = 2 * PP_BYTES + 3 * PW_BYTES;     // 153600
-constexpr int PRED = PRING;                 // column-statistics scratch: [4 row groups][128 channels][2] floats
-constexpr int PBIAS = PRED + 4 * 128 * 2 * 4;          // bias of the workgroup's 128 channels
-constexpr int PSMEM = PBIAS + 128 * 4;                 // 158208
+constexpr int PRED = PRING;                 // column-statistics scratch: 2 buffers x [4 row groups][128 channels][2] floats
+constexpr int PRED_BYTES = 4 * 128 * 2 * 4;
+constexpr int PBIAS = PRED + 2 * PRED_BYTES;           // bias of the workgroup's 128 channels
+constexpr int PSCHED = PBIAS + 128 * 4;                // tile tickets handed from thread 0 to the workgroup
+constexpr int PSMEM = PSCHED + 16;                     // 158224
 constexpr uint32_t OOB = 0xF0000000u;
 
-struct Tile { int img, y0, x0, n0; };
+struct Tile { int img, y0, x0, n0, pix; };
 }  // namespace
 
 // abl (ablation build only): 1 no patch DMA, 8 no kernel DMA (after the prologue), 2 no output stores, 4 no MFMA loop
-__global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd, int abl) {
+__global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd, unsigned* sched, int abl) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[PSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -76,16 +78,27 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
 
     // ---- tiles of this workgroup.  Job index = pixel tile * ntN + channel tile; XCD x (= blockIdx & 7) owns per_xcd pixel
     // tiles; its 32 workgroups take jobs slot, slot + 32, ...: ntN divides 32, so a workgroup keeps channel tile slot % ntN.
+    //
+    // WHICH pixel tile of its XCD range a workgroup takes next is decided at run time: the 32 / ntN workgroups of a group (XCD,
+    // channel tile) draw tickets from one counter (kernels.h, SchedSlot).  With a fixed assignment a workgroup that cannot be placed
+    // at once - a CU held by another kernel: a collective beside the backward pass, a weight-gradient kernel of the side
+    // stream - leaves its tiles for a second round after everybody else has finished (measured with 32 of 256 CUs held:
+    // 1.6x the launch time; the per-tile kernel: 1.0-1.26x).  With tickets the workgroups that do run share all tiles.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int job0 = xcd * per_xcd * ntN, job_end = min(pix_tiles, (xcd + 1) * per_xcd) * ntN;
-    int job = job0 + slot;
     const int nt = slot % ntN, n0 = nt * PBN;
-    auto tile_of = [&](int jb) {
+    const int pt0 = xcd * per_xcd, cnt = max(0, min(pix_tiles, (xcd + 1) * per_xcd) - pt0);
+    unsigned* ctr = sched ? sched + xcd * 8 + nt : nullptr;
+    int kstat = 0;                                        // sched == nullptr: the fixed assignment q, q + 32 / ntN, ...
+    auto take = [&]() -> unsigned {                       // thread 0 only
+        if (ctr) return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)(slot / ntN + (kstat++) * (32 / ntN));
+    };
+    auto tile_of = [&](unsigned ticket) {
         Tile t;
-        int id = jb / ntN;
+        int id = pt0 + (int)ticket;
         const int tx = id % tiles_x; id /= tiles_x;
         const int ty = id % tiles_y;
-        t.img = id / tiles_y; t.y0 = ty * PTR; t.x0 = tx * 32; t.n0 = n0;
+        t.img = id / tiles_y; t.y0 = ty * PTR; t.x0 = tx * 32; t.n0 = n0; t.pix = pt0 + (int)ticket;
         return t;
     };
 
@@ -151,21 +164,50 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
 
     __bf16* __restrict__ out = (__bf16*)a.out;
     const __bf16* __restrict__ addend = (const __bf16*)a.addend;
-    // colstat row: the ntN workgroups slot = q * ntN + nt of an XCD fill row xcd * (32 / ntN) + q together
-    const size_t cs_row = (size_t)xcd * (32 / ntN) + slot / ntN;
     // ---- LDS scratch behind the rings: column statistics [4 row groups][128 channels][2] (each word has ONE owner lane, which adds
     // to it tile after tile: deterministic without atomics across lanes) and the bias of the workgroup's 128 channels
     {
         float* red = reinterpret_cast<float*>(smem + PRED);
-        for (int i = tid; i < 4 * 128 * 2; i += 512) red[i] = 0.f;
+        if (tid == 0) {                                   // the first two tickets
+            unsigned* tk = reinterpret_cast<unsigned*>(smem + PSCHED);
+            tk[0] = take(); tk[1] = take();
+        }
+        (void)red;
         if (tid < 128) reinterpret_cast<float*>(smem + PBIAS)[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
     }
     __syncthreads();
     const uint32_t bias_a = lds0 + PBIAS + (uint32_t)((wn * 64 + 8 * lq) * 4);
-    const uint32_t red_a = lds0 + PRED + (uint32_t)(((wm * 128) + wn * 64 + 8 * lq) * 8);
+    const uint32_t red_a = lds0 + PRED + (uint32_t)(((wm * 128) + wn * 64 + 8 * lq) * 8);        // + buffer * PRED_BYTES
+    // column statistics of a finished tile: its 4 row groups leave their sums in LDS buffer (tile parity); behind the next barrier
+    // 256 threads add the four in a fixed order and write the tile's row - one row per pixel tile whoever served it
+    int cs_pending = -1, cs_par = 0;                     // pixel tile whose sums wait in buffer cs_par ^ 1
+    auto flush_row = [&](int pix_tile, int buf) {
+        if (tid < 256) {
+            const int ch = tid >> 1, st = tid & 1;
+            const uint32_t ra = lds0 + PRED + buf * PRED_BYTES + (uint32_t)((ch * 2 + st) * 4);
+            float r0, r1, r2, r3;
+            asm volatile("ds_read_b32 %0, %1 offset:0" : "=v"(r0) : "v"(ra));
+            asm volatile("ds_read_b32 %0, %1 offset:1024" : "=v"(r1) : "v"(ra));
+            asm volatile("ds_read_b32 %0, %1 offset:2048" : "=v"(r2) : "v"(ra));
+            asm volatile("ds_read_b32 %0, %1 offset:3072" : "=v"(r3) : "v"(ra));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const float t = ((r0 + r1) + r2) + r3;
+            if (n0 + ch < a.N) a.colstat[((size_t)pix_tile * a.N + n0 + ch) * 2 + st] = t;
+        }
+    };
 
-    if (job < job_end) {
-        Tile cur = tile_of(job);
+    const uint32_t sched_a = lds0 + PSCHED;
+    const unsigned tk0 = reinterpret_cast<const unsigned*>(smem + PSCHED)[0], tk1 = reinterpret_cast<const unsigned*>(smem + PSCHED)[1];
+    __syncthreads();                                      // (thread 0 reuses word 2 below)
+    if (tk0 < (unsigned)cnt) {
+        Tile cur = tile_of(tk0);
+        bool have_next = tk1 < (unsigned)cnt;           // a next tile is known to exist
+        bool pending = false;                             // its ticket is still on its way (drawn in the last epilogue)
+        Tile nxt = cur;
+        __amdgpu_buffer_rsrc_t rs_nxt = image_rsrc(cur.img);
+        if (have_next) { nxt = tile_of(tk1); rs_nxt = image_rsrc(nxt.img); }
+        const uint64_t ctr_addr = (uint64_t)(uintptr_t)ctr;
         __amdgpu_buffer_rsrc_t rs_cur = image_rsrc(cur.img);
         // ---- prologue of the first tile only: patch 0, kernel steps 0 and 1
         issue_p(rs_cur, cur, 0, 0);
@@ -179,11 +221,6 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
         int pbuf = 0;                                     // patch buffer of the current chunk
         int nst_prev = 0;                                 // output stores issued by this wave just before the current step
         for (;;) {
-            const int njob = job + 32;
-            const bool have_next = njob < job_end;
-            Tile nxt = cur;
-            __amdgpu_buffer_rsrc_t rs_nxt = rs_cur;
-            if (have_next) { nxt = tile_of(njob); rs_nxt = image_rsrc(nxt.img); }
 
             f32x4 acc[4][2][4];                           // [image row][16-pixel half][16-channel tile]
 #pragma unroll
@@ -199,6 +236,19 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
                 const int nch_ = last ? 0 : ch + 1;       // its chunk index
 #pragma unroll 1
                 for (int dx = 0; dx < 3; ++dx) {
+                    // ---- the next tile's ticket (drawn during the previous tile's epilogue, handed over through LDS behind the
+                    //      barrier of this tile's first step)
+                    if (ch == 0 && dx == 1 && cs_pending >= 0) { flush_row(cs_pending, cs_par ^ 1); cs_pending = -1; }
+                    if (ch == 0 && dx == 1 && pending) {
+                        unsigned v;
+                        asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(v) : "v"(sched_a));
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                        have_next = tk < (unsigned)cnt;
+                        if (have_next) { nxt = tile_of(tk); rs_nxt = image_rsrc(nxt.img); }
+                        pending = false;
+                    }
                     // ---- prefetch: kernel tile of step s+2 (ring slot (dx+2)%3), patch of the next chunk
                     if (dx == 0) {
                         issue_w(ch, 2, 2);
@@ -257,6 +307,15 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
 
             // ---- epilogue straight from the accumulators: acc[i][h][t][e] = D[row 4 lq + e of tile t][pixel 16 h + l15] of image
             //      row y0 + 4 wm + i; with the permuted kernel rows, tiles (2m, 2m+1) of a lane are channels 32 m + 8 lq + 0..7
+            // ---- the ticket of the tile after next: thread 0 draws it now (a returning atomic: 1-2 us) and hands it over at the end of
+            //      the epilogue, when only the output stores issued in between are younger (inline asm on both ends: the compiler's
+            //      own atomic sequence waits vmcnt(0) on the spot, i.e. for every DMA and store in flight)
+            const bool draw = have_next;                 // no further draw after the first ticket past the end
+            unsigned tk_mine = 0xFFFFFFFFu;
+            if (draw && tid == 0) {
+                if (ctr) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(tk_mine) : "v"(ctr_addr), "v"(1u) : "memory");
+                else tk_mine = (unsigned)(slot / ntN + (kstat++) * (32 / ntN));
+            }
             int nst = 0;
             const int nb = n0 + wn * 64 + 8 * lq;
             float bias_[2][8];
@@ -334,6 +393,10 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
                 }
             }
             nst_prev = nst;
+            if (draw && tid == 0) {
+                if (nst == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("ds_write_b32 %0, %1 offset:8" :: "v"(sched_a), "v"(tk_mine) : "memory");
+            }
             if (a.colstat) {
                 // over the 16 pixel columns of the lane group; lane l15 == 0 then adds to the words it owns (inline asm: an LDS
                 // access the compiler can see would make it drain the DMA queue and the stores first)
@@ -347,28 +410,33 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            asm volatile("ds_add_f32 %0, %1 offset:%2" :: "v"(red_a), "v"(cs_s[m][e]), "n"((32 * m + e) * 8) : "memory");
-                            asm volatile("ds_add_f32 %0, %1 offset:%2" :: "v"(red_a), "v"(cs_q[m][e]), "n"((32 * m + e) * 8 + 4) : "memory");
+                            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(red_a + cs_par * PRED_BYTES), "v"(cs_s[m][e]), "n"((32 * m + e) * 8) : "memory");
+                            asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(red_a + cs_par * PRED_BYTES), "v"(cs_q[m][e]), "n"((32 * m + e) * 8 + 4) : "memory");
                         }
                 }
+                cs_pending = cur.pix;
+                cs_par ^= 1;
             }
             if (!have_next) break;
-            job = njob;
             cur = nxt;
             rs_cur = rs_nxt;
+            pending = draw;                               // whether a tile follows `cur` is known after its first step
+            have_next = false;
         }
     }
 
     // ---- column statistics of this workgroup's channel tile: over the 16 pixel columns of a lane group, then the 4 row groups
-    if (a.colstat) {
+    if (a.colstat && cs_pending >= 0) {                   // the last tile's row
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* red = reinterpret_cast<const float*>(smem + PRED);      // [4 wm][128 ch][2]
-        if (tid < 256) {
-            const int ch = tid >> 1, st = tid & 1;
-            const float t = ((red[(0 * 128 + ch) * 2 + st] + red[(1 * 128 + ch) * 2 + st]) + red[(2 * 128 + ch) * 2 + st]) +
-                            red[(3 * 128 + ch) * 2 + st];
-            if (n0 + ch < a.N) a.colstat[(cs_row * a.N + n0 + ch) * 2 + st] = t;
+        flush_row(cs_pending, cs_par ^ 1);
+    }
+    // ---- the last workgroup to leave clears the launch's counters for the next launch on this stream (every workgroup has
+    //      drawn its last - failing - ticket before it counts itself out)
+    if (sched && tid == 0) {
+        const unsigned d = __hip_atomic_fetch_add(sched + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == gridDim.x - 1) {
+            for (int i = 0; i < 65; ++i) __hip_atomic_store(sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -379,15 +447,15 @@ inline long long pixel_tiles(const Conv3Args& a) { return (long long)a.B * ((a.H
 
 bool conv3x3p_applies(const Conv3Args& a) {
     const int ntN = (a.N + PBN - 1) / PBN;
-    return unetrir_cfg().conv3x3p && conv3x3g_applies(a) && !conv3x3g_pair_applies(a) && (a.N & 7) == 0 &&
+    return unetrir_cfg().conv3x3p && conv3x3g_applies(a) && !conv3x3g_pair_applies(a) && (a.N & 7) == 0 && a.C >= 64 &&
            (ntN == 1 || ntN == 2 || ntN == 4 || ntN == 8) && pixel_tiles(a) * ntN >= 512;
 }
 
-long long conv3x3p_colstat_rows(const Conv3Args& a) { return 256 / ((a.N + PBN - 1) / PBN); }
+long long conv3x3p_colstat_rows(const Conv3Args& a) { return pixel_tiles(a); }
 
 int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s) {
     const long long pt = pixel_tiles(a);
     const int per_xcd = (int)((pt + 7) / 8);
-    hipLaunchKernelGGL(conv3x3p_bf16_kernel, dim3(256), dim3(512), 0, s, a, (int)pt, per_xcd, UNETRIR_ABL_HOST());
+    hipLaunchKernelGGL(conv3x3p_bf16_kernel, dim3(256), dim3(512), 0, s, a, (int)pt, per_xcd, sched_slot(s), UNETRIR_ABL_HOST());
     return (int)hipGetLastError();
 }

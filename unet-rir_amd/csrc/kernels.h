@@ -142,6 +142,10 @@ bool conv3x3_has_colstat(const Conv3Args& a);
 bool conv3x3s_applies(const Conv3Args& a);          // 64 -> 64 channels: strip kernel with the whole 3x3 kernel resident in LDS
 long long conv3x3s_colstat_rows(const Conv3Args& a);
 int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
+// Run-time tile tickets of the persistent kernels: 64 group counters + 1 count of finished workgroups, zero between launches.
+// One slot per stream (launches on a stream run in order; the last workgroup of a launch clears the slot); nullptr when more
+// than 128 streams are in use - the kernels then keep their fixed assignment.
+unsigned* sched_slot(hipStream_t s);
 bool conv3x3p_applies(const Conv3Args& a);          // conv3x3g's layers with >= 512 tiles: persistent form, continuous K loop across tiles
 long long conv3x3p_colstat_rows(const Conv3Args& a);
 int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s);

@@ -119,6 +119,14 @@ def conv2d_colstat_rows(g, dgrad, x: Act):
     return int(_lib.lib().unetrir_conv2d_colstat_rows_bf16(C.byref(g), int(bool(dgrad)), x.ld))
 
 
+K3_NAMES = ("tap-table", "conv3x3r", "conv3x3g", "conv3x3g pair", "conv3x3h", "conv3x3s", "conv3x3p", "stem")
+
+
+def conv3x3_kernel(g, dgrad, x: Act):
+    """Name of the kernel that serves this 3x3 stride-1 layer (bf16 storage) under the switches in effect."""
+    return K3_NAMES[int(_lib.lib().unetrir_conv3x3_kernel_id_bf16(C.byref(g), int(bool(dgrad)), x.ld))]
+
+
 def conv2d_fwd_colstat(g, x: Act, w, bias, y: Act, colstat, addend: Act = None):
     """conv2d_fwd that also writes per-tile (sum, sum of squares) of the stored output: colstat [rows][Cout][2] fp32."""
     check(_lib.lib().unetrir_conv2d_fwd_colstat_bf16(C.byref(g), _p(x), x.ld, _p(w), _p(bias), _p(addend),
