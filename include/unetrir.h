@@ -71,10 +71,11 @@ int unetrir_abi_version(void);
  *        wgrad3x3d      UNETRIR_WGRAD3X3D      bf16 LDS-DMA 3x3 stride-2 weight gradient (wgrad3x3d.hip)
  *        conv3x3d       UNETRIR_CONV3X3D       bf16 LDS-DMA 3x3 stride-2 forward / transposed data gradient (conv3x3d.hip)
  *        conv3x3p       UNETRIR_CONV3X3P       bf16 persistent form of conv3x3g for layers with >= 512 tiles (conv3x3p.hip)
- *        upconv3x3q     UNETRIR_UPCONV3X3Q     bf16 persistent form of upconv3x3g for layers with >= 512 tiles (upconv3x3q.hip) */
+ *        upconv3x3q     UNETRIR_UPCONV3X3Q     bf16 persistent form of upconv3x3g for layers with >= 512 tiles (upconv3x3q.hip)
+ *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q;
+        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);

@@ -27,6 +27,7 @@ unetrir_config load_config() {
     c.conv3x3d = env_int("UNETRIR_CONV3X3D", 1);
     c.conv3x3p = env_int("UNETRIR_CONV3X3P", 1);
     c.upconv3x3q = env_int("UNETRIR_UPCONV3X3Q", 1);
+    c.dyn_tiles = env_int("UNETRIR_DYN_TILES", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     return c;
 }
@@ -73,6 +74,7 @@ unsigned* sched_slot(hipStream_t s) {
     static hipStream_t owner[128];
     static int used = 0;
     static unsigned* base = nullptr;
+    if (!unetrir_cfg().dyn_tiles) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     if (!base) {
         void* p = nullptr;

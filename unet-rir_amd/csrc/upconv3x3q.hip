@@ -13,8 +13,8 @@
 //   * an addend (the skip-connection gradient the strided convolution's data gradient accumulates into, in place) is loaded
 //     before those requests, into the registers the K loop's fragments have just left;
 //   * tiles are dealt to the XCDs in contiguous ranges, channel tile fastest; a workgroup keeps one channel tile.
-// K loop, LDS images, swizzles as upconv3x3g.hip.  Requires C % 32 == 0, C >= 64, N % 8 == 0, N / 64 tiles in {1, 2, 4, 8},
-// at least 512 tiles; otherwise upconv3x3g.
+// K loop, LDS images, swizzles as upconv3x3g.hip.  Requires C % 32 == 0, C >= 96 (three K steps per tile), N % 8 == 0, N / 64 tiles in {1, 2, 4, 8},
+// at least 1024 tiles (four per workgroup: with two the ticket draws at start-up cost what the persistence gains); otherwise upconv3x3g.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -40,13 +40,14 @@ constexpr int QW_INSTR = 9 * QBN / 16;         // 36: [9 taps][64 channels] rows
 constexpr int QW_BYTES = QW_INSTR * 1024;      // 36864
 constexpr int QRING = 3 * QP_BYTES + 2 * QW_BYTES;   // 132096
 constexpr int QBIAS = QRING;                   // bias of the workgroup's 64 channels
-constexpr int QSMEM = QBIAS + QBN * 4;
+constexpr int QSCHED = QBIAS + QBN * 4;          // tile tickets handed from thread 0 to the workgroup
+constexpr int QSMEM = QSCHED + 16;
 constexpr uint32_t QOOB = 0xF0000000u;
 
 struct Tile { int img, y0, x0; };
 }  // namespace
 
-__global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd) {
+__global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd, unsigned* sched) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[QSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -61,21 +62,42 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
 
     // ---- tiles of this workgroup (see conv3x3p.hip): job = pixel tile * ntN + channel tile, XCD-contiguous ranges
+    //      which pixel tile of its group (XCD, channel tile) a workgroup takes next is decided at run time by tickets (kernels.h,
+    //      sched_slot; conv3x3p.hip has the why)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int job_end = min(pix_tiles, (xcd + 1) * per_xcd) * ntN;
-    int job = xcd * per_xcd * ntN + slot;
-    const int n0 = (slot % ntN) * QBN;
-    auto tile_of = [&](int jb) {
+    const int nt = slot % ntN, n0 = nt * QBN;
+    const int pt0 = xcd * per_xcd, cnt = max(0, min(pix_tiles, (xcd + 1) * per_xcd) - pt0);
+    unsigned* ctr = sched ? sched + xcd * 8 + nt : nullptr;
+    int kstat = 0;                                        // sched == nullptr: the fixed assignment q, q + 32 / ntN, ...
+    auto take = [&]() -> unsigned {                       // thread 0 only
+        if (ctr) return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)(slot / ntN + (kstat++) * (32 / ntN));
+    };
+    auto tile_of = [&](unsigned ticket) {
         Tile t;
-        int id = jb / ntN;
+        int id = pt0 + (int)ticket;
         const int tx = id % tiles_x; id /= tiles_x;
         const int ty = id % tiles_y;
         t.img = id / tiles_y; t.y0 = ty * QR; t.x0 = tx * QC;
         return t;
     };
     if (tid < QBN) reinterpret_cast<float*>(smem + QBIAS)[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
+    if (tid == 0) {                                       // the first two tickets
+        unsigned* tk = reinterpret_cast<unsigned*>(smem + QSCHED);
+        tk[0] = take(); tk[1] = take();
+    }
     __syncthreads();
-    if (job >= job_end) return;
+    const unsigned tk0 = reinterpret_cast<const unsigned*>(smem + QSCHED)[0], tk1 = reinterpret_cast<const unsigned*>(smem + QSCHED)[1];
+    // the last workgroup to leave clears the launch's counters (every workgroup has drawn its last - failing - ticket by then)
+    auto leave = [&]() {
+        if (sched && tid == 0) {
+            const unsigned d = __hip_atomic_fetch_add(sched + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1)
+                for (int i = 0; i < 65; ++i) __hip_atomic_store(sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (tk0 >= (unsigned)cnt) { leave(); return; }
+    const uint32_t sched_a = lds0 + QSCHED;
 
     // ---- per-lane DMA sources
     const int slot4 = lane & 3, sub = lane >> 2;
@@ -145,9 +167,12 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
     const __bf16* __restrict__ addend = (const __bf16*)a.addend;
     const int nb = n0 + wn * 32 + 8 * lq;              // this lane's 8 channels
 
-    Tile cur = tile_of(job);
-    bool have_next = job + 32 < job_end;
-    Tile nxt = have_next ? tile_of(job + 32) : cur;
+    Tile cur = tile_of(tk0);
+    bool have_next = tk1 < (unsigned)cnt;
+    Tile nxt = have_next ? tile_of(tk1) : cur;
+    bool drawing = have_next;                            // tickets are drawn until the first one past the end
+    bool have_nn = false;                                // the tile after `nxt` (drawn in this tile's first step, known from its second)
+    unsigned tk_nn = 0;
     // (tile, chunk) of the step k ahead of (cur, ch), k = 1, 2 (nch >= 2): this tile's or the next one's
     // ---- prologue of the first tile: patch 0, kernel 0, patch 1
     issue_p(cur, 0, 0);
@@ -178,6 +203,24 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
             //      of the step leaves them in flight.  With an addend its loads would wait for the requests ahead of them, so the
             //      epilogue runs first (its loads wait for nothing but the patch the next step needs anyway).
             const bool do_epi = epi && ch == 0;
+            // ---- tickets: thread 0 draws the one after next in a tile's first step (returning atomic as inline asm: the compiler's own
+            //      sequence would wait vmcnt(0) on the spot), hands it over behind that step's counted wait, everybody reads it in the second
+            unsigned tk_mine = 0xFFFFFFFFu;
+            const bool draw = drawing && ch == 0;
+            if (draw && tid == 0) {
+                if (ctr) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(tk_mine) : "v"((uint64_t)(uintptr_t)ctr), "v"(1u) : "memory");
+                else tk_mine = (unsigned)(slot / ntN + (kstat++) * (32 / ntN));
+            }
+            if (drawing && ch == 1) {
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(v) : "v"(sched_a));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                have_nn = tk < (unsigned)cnt;
+                tk_nn = tk;
+                drawing = have_nn;
+            }
             const bool more1 = ch + 1 < nch || have_next, more2 = ch + 2 < nch || have_next;
             auto prefetch = [&]() {
                 if (more1) issue_w(ch + 1 < nch ? ch + 1 : 0, (g + 1) & 1);
@@ -250,18 +293,20 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
 
             const uint32_t ab0 = a_lane[0] + pslot * QP_BYTES, ab1 = a_lane[1] + pslot * QP_BYTES;
             const uint32_t bb = b_lane + (g & 1) * QW_BYTES;
-            u32x4 pf[3][2][2];
-#define RDP(r) DSR128(pf[r][0][0], ab0, (r) * (QPC * 64)); DSR128(pf[r][0][1], ab0, (r) * (QPC * 64) + 1024); \
-               DSR128(pf[r][1][0], ab1, (r) * (QPC * 64)); DSR128(pf[r][1][1], ab1, (r) * (QPC * 64) + 1024)
-            RDP(0); RDP(1); RDP(2);
-#undef RDP
+            // patch rows: taps kh = 0, 1 pair output row i with patch row i + 1 (rows 1, 2), taps kh = 2 with patch row i (rows 0, 1):
+            // row 2 is dead after the kh = 1 taps and row 0 is read into its registers - 8 fragments live instead of 12
+            u32x4 pf[2][2][2];                             // [0]: patch row 1;  [1]: patch row 2, then row 0
+#define RDP(slot, r) DSR128(pf[slot][0][0], ab0, (r) * (QPC * 64)); DSR128(pf[slot][0][1], ab0, (r) * (QPC * 64) + 1024); \
+                     DSR128(pf[slot][1][0], ab1, (r) * (QPC * 64)); DSR128(pf[slot][1][1], ab1, (r) * (QPC * 64) + 1024)
+            RDP(0, 1); RDP(1, 2);
             __builtin_amdgcn_s_setprio(1);
 #define RDW(W0, W1, T9) do { DSR128(W0, bb, (T9) * 4096); DSR128(W1, bb, (T9) * 4096 + 1024); } while (0)
+            // tap (KH, KW), output row i: kh < 2 -> slot i (rows 1, 2); kh = 2 -> slot 1 - i (row 0 sits in slot 1, row 1 in slot 0)
 #define MMT(KH, KW, W0, W1)                                                                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
             _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
-                MMA16(acc[((KH) & 1) * 2 + ((KW) & 1)][i][h][0], W0, pf[i + 1 - ((KH) >> 1)][(KW) >> 1][h]);     \
-                MMA16(acc[((KH) & 1) * 2 + ((KW) & 1)][i][h][1], W1, pf[i + 1 - ((KH) >> 1)][(KW) >> 1][h]);     \
+                MMA16(acc[((KH) & 1) * 2 + ((KW) & 1)][i][h][0], W0, pf[(KH) < 2 ? i : 1 - i][(KW) >> 1][h]);     \
+                MMA16(acc[((KH) & 1) * 2 + ((KW) & 1)][i][h][1], W1, pf[(KH) < 2 ? i : 1 - i][(KW) >> 1][h]);     \
             }
             u32x4 wa0, wa1, wb0, wb1;
             RDW(wa0, wa1, 0);
@@ -271,9 +316,12 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
             RDW(wa0, wa1, 4); LGKM_WAIT(2); MMT(1, 0, wb0, wb1);
             RDW(wb0, wb1, 5); LGKM_WAIT(2); MMT(1, 1, wa0, wa1);
             RDW(wa0, wa1, 6); LGKM_WAIT(2); MMT(1, 2, wb0, wb1);
+            __builtin_amdgcn_sched_barrier(0);             // the reads below overwrite row 2: not above its last MFMAs
+            RDP(1, 0);
             RDW(wb0, wb1, 7); LGKM_WAIT(2); MMT(2, 0, wa0, wa1);
             RDW(wa0, wa1, 8); LGKM_WAIT(2); MMT(2, 1, wb0, wb1);
             LGKM_WAIT(0); MMT(2, 2, wa0, wa1);
+#undef RDP
 #undef MMT
 #undef RDW
             __builtin_amdgcn_s_setprio(0);
@@ -282,6 +330,7 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
             //      the output stores issued after it stay in flight
             if (more2) { if (nst == 16) asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (draw && tid == 0) asm volatile("ds_write_b32 %0, %1 offset:8" :: "v"(sched_a), "v"(tk_mine) : "memory");   // (older than every request of the step)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ++g;
@@ -291,10 +340,10 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
         prev = cur;
         epi = true;
         if (!have_next) break;
-        job += 32;
         cur = nxt;
-        have_next = job + 32 < job_end;
-        if (have_next) nxt = tile_of(job + 32);
+        if (have_nn) nxt = tile_of(tk_nn);
+        have_next = have_nn;
+        have_nn = false;
     }
     // ---- the last tile's epilogue (no DMA in flight any more)
     {
@@ -329,6 +378,7 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
                     *reinterpret_cast<bf16x8*>(out + pix * a.ldo + nb) = ov;
                 }
     }
+    leave();
 }
 
 namespace {
@@ -338,14 +388,14 @@ inline long long q_pixel_tiles(const Conv3Args& a) { return (long long)a.B * ((a
 bool upconv3x3q_applies(const Conv3Args& a) {
     const int ntN = (a.N + QBN - 1) / QBN;
     const size_t out_bytes = (((size_t)4 * a.H * a.W - 1) * a.ldo + a.N) * 2;
-    return unetrir_cfg().upconv3x3q && upconv3x3g_applies(a) && a.C >= 64 && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
-           (!a.addend || (a.ldadd & 7) == 0) && (ntN == 1 || ntN == 2 || ntN == 4 || ntN == 8) && q_pixel_tiles(a) * ntN >= 512 &&
+    return unetrir_cfg().upconv3x3q && upconv3x3g_applies(a) && a.C >= 96 && (a.N & 7) == 0 && (a.ldo & 7) == 0 &&
+           (!a.addend || (a.ldadd & 7) == 0) && (ntN == 1 || ntN == 2 || ntN == 4 || ntN == 8) && q_pixel_tiles(a) * ntN >= 1024 &&
            out_bytes < 0x70000000u;
 }
 
 int launch_upconv3x3q_bf16(const Conv3Args& a, hipStream_t s) {
     const long long pt = q_pixel_tiles(a);
     const int per_xcd = (int)((pt + 7) / 8);
-    hipLaunchKernelGGL(upconv3x3q_bf16_kernel, dim3(256), dim3(512), 0, s, a, (int)pt, per_xcd);
+    hipLaunchKernelGGL(upconv3x3q_bf16_kernel, dim3(256), dim3(512), 0, s, a, (int)pt, per_xcd, sched_slot(s));
     return (int)hipGetLastError();
 }
