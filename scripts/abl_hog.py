@@ -44,3 +44,18 @@ for (Cc, N, HW) in ((128, 128, 128), (256, 256, 64)):
         ops.set_config(conv3x3p=p_on)
         t0, t1 = timed(fn, False), timed(fn, True)
         print(f"{Cc}->{N}@{HW} {'persistent' if p_on else 'per-tile  '}: alone {t0:7.1f} us, beside {n_hog} x {lds} B workgroups {t1:7.1f} us ({t1/t0:.2f}x)", flush=True)
+
+
+# the stride-2 pair: conv3x3d (down direction) and upconv3x3q (up direction) against the kernels they replaced
+for (Cc, N, HW) in ((64, 128, 256), (128, 256, 128)):
+    x = ops.Act((torch.rand((B, HW, HW, Cc), device=dev) - 0.5).to(dt))
+    w = ((torch.rand((N, 9, Cc), device=dev) - 0.5) * 0.1).to(dt)
+    wt = ((torch.rand((Cc, 9, N), device=dev) - 0.5) * 0.1).to(dt)
+    y = ops.Act(torch.empty((B, HW // 2, HW // 2, N), device=dev, dtype=dt))
+    g = ops.geom(B, HW, HW, Cc, N, 3, 2)
+    for name, sw, fn in (("conv3x3d  ", "conv3x3d", lambda: ops.conv2d_fwd(g, x, w, None, y)), ("upconv3x3q", "upconv3x3q", lambda: ops.conv2d_dgrad(g, y, wt, x))):
+        for on in (1, 0):
+            ops.set_config(**{sw: on})
+            t0, t1 = timed(fn, False), timed(fn, True)
+            print(f"{Cc}<->{N}@{HW} {name} {'on ' if on else 'off'}: alone {t0:7.1f} us, beside {n_hog} x {lds} B workgroups {t1:7.1f} us ({t1/t0:.2f}x)", flush=True)
+        ops.set_config(**{sw: 1})

@@ -24,7 +24,7 @@
 //     the same patch (the N / 128 channel blocks of a tile) run at the same time on one XCD and share it in that L2.
 // 16-byte granules of a 32-byte pixel are swapped where bit 3 of the pixel's row position is set (conflict-free ds_read_b128),
 // on the DMA source granule and on the read address.  Out-of-image pixels carry a buffer offset past num_records and read
-// zeros.  Requires even input sizes, OH % 8 == 0, OW % 32 == 0, C % 16 == 0, N % 32 == 0 (conv3x3d_applies).
+// zeros.  Requires even input sizes, OH % 8 == 0, OW % 32 == 0, C % 16 == 0, C >= 32, N % 32 == 0 (conv3x3d_applies).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -49,8 +49,9 @@ constexpr int DW_INSTR = 36;                    // [9 taps][4 blocks of 32 chann
 constexpr int DP_BYTES = DP_INSTR * 1024, DW_BYTES = DW_INSTR * 1024;
 constexpr int DROW = DPW * 32;                  // 2112
 constexpr int DBIAS = 2 * (DP_BYTES + DW_BYTES);            // 147456
-constexpr int DMAXN = 4096;
-constexpr int DSMEM = DBIAS + DMAXN * 4;        // 163840
+constexpr int DMAXN = 4064;                      // output channels whose bias fits beside the rings (and 16 bytes of tile tickets)
+constexpr int DSCHED = DBIAS + DMAXN * 4;       // tile tickets handed from thread 0 to the workgroup
+constexpr int DSMEM = DSCHED + 16;              // 163728
 constexpr uint32_t OOB = 0xF0000000u;
 static_assert(DP_INSTR + DW_INSTR == 72, "nine DMA instructions per wave and step");
 
@@ -60,7 +61,7 @@ struct Job { int img, oy0, ox0, n0, redge; uint32_t pbase, wbase; };
 // a.H, a.W: INPUT size (even); output a.H / 2 x a.W / 2
 // abl (ablation build only): 1 no patch DMA, 8 no kernel DMA (after the first step), 2 no output stores, 4 no MFMA loop,
 // 16 / 32 kernel / patch DMA pieces read contiguous memory (wrong data: what the 32-byte gather granularity costs)
-__global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a, int njobs, int abl) {
+__global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a, int njobs, unsigned* sched, int abl) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[DSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,23 +75,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
 
     // ---- jobs of this workgroup: XCD x (= blockIdx & 7 under round-robin dispatch) owns a contiguous range of the job list
-    int job, job_end, job_step;
+    //      which job of its XCD's range a workgroup takes next is decided at run time by tickets (kernels.h, sched_slot; conv3x3p.hip
+    //      has the why); grids that are not a multiple of 8 (fewer jobs than CUs) keep the fixed assignment
+    int job0, cnt, kstep, kfirst;                     // range start, jobs in the range; fixed assignment: kfirst, kfirst + kstep, ...
+    unsigned* ctr = nullptr;
     if ((gridDim.x & 7) == 0) {
         const int per = (njobs + 7) >> 3, xcd = blockIdx.x & 7;
-        job = xcd * per + (int)(blockIdx.x >> 3);
-        job_end = min(njobs, (xcd + 1) * per);
-        job_step = (int)(gridDim.x >> 3);
+        job0 = xcd * per; cnt = max(0, min(njobs, (xcd + 1) * per) - job0);
+        kfirst = (int)(blockIdx.x >> 3); kstep = (int)(gridDim.x >> 3);
+        if (sched) ctr = sched + xcd * 8;
     } else {
-        job = blockIdx.x; job_end = njobs; job_step = gridDim.x;
+        job0 = 0; cnt = njobs; kfirst = blockIdx.x; kstep = gridDim.x;
     }
+    int kstat = 0;
 
     // ---- bias of all output channels, once
     {
         float* bl = reinterpret_cast<float*>(smem + DBIAS);
         for (int n = tid; n < a.N; n += 512) bl[n] = a.bias ? a.bias[n] : 0.f;
+        if (tid == 0) {                               // the first two tickets (one round trip)
+            unsigned* tk = reinterpret_cast<unsigned*>(smem + DSCHED);
+            if (ctr) { const unsigned t = __hip_atomic_fetch_add(ctr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tk[0] = t; tk[1] = t + 1; }
+            else { tk[0] = (unsigned)kfirst; tk[1] = (unsigned)(kfirst + kstep); kstat = 2; }
+        }
     }
     __syncthreads();
-    if (job >= job_end) return;
+    const unsigned tk0 = reinterpret_cast<const unsigned*>(smem + DSCHED)[0], tk1 = reinterpret_cast<const unsigned*>(smem + DSCHED)[1];
+    // the last workgroup to leave clears the launch's counters (every workgroup has drawn its last - failing - ticket by then)
+    auto leave = [&]() {
+        if (sched && (gridDim.x & 7) == 0 && tid == 0) {
+            const unsigned d = __hip_atomic_fetch_add(sched + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1)
+                for (int i = 0; i < 65; ++i) __hip_atomic_store(sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (tk0 >= (unsigned)cnt) { leave(); return; }
+    const uint32_t sched_a = lds0 + DSCHED;
 
     // ---- DMA lane constants.  Combined instruction index i = wave + 8 j (j = 0..8): i < 36 patch instruction i, else kernel
     // block i - 36.  Patch instruction i covers LDS pixels 32 i .. 32 i + 31, lane = (pixel sub, 16-byte slot).
@@ -187,7 +207,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
     __bf16* __restrict__ out = (__bf16*)a.out;
     const __bf16* __restrict__ addend = (const __bf16*)a.addend;
 
-    Job cur = job_params(job);
+    Job cur = job_params(job0 + (int)tk0);
+    bool have_next = tk1 < (unsigned)cnt;           // a next job is known to exist
+    Job nxt = have_next ? job_params(job0 + (int)tk1) : cur;
+    bool pending = false;                             // the next job's ticket is on its way (drawn in the last job's last step)
+    bool drawing = have_next;                         // tickets are drawn until the first one past the end
     {
         const Src s0 = step_src(cur, 0, 1);
 #pragma unroll
@@ -197,10 +221,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
     int par = 0;
     bool pend = false;                                // output stores issued after the newest DMAs
     for (;;) {
-        const int njob = job + job_step;
-        const bool have_next = njob < job_end;
-        Job nxt = cur;
-        if (have_next) nxt = job_params(njob);
         f32x16 acc[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o)
@@ -215,6 +235,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
             pend = false;
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            // ---- tickets.  The next job's: handed over through LDS in the last epilogue, read behind this job's first barrier.  The one
+            //      after: thread 0 draws it at the start of this job's LAST step (returning atomic as inline asm: the compiler's own
+            //      sequence waits vmcnt(0) on the spot) and waits for it at the end of that step, leaving the step's 9 DMA pieces in flight.
+            if (ch == 0 && pending) {
+                unsigned v;
+                asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(v) : "v"(sched_a));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                have_next = tk < (unsigned)cnt;
+                if (have_next) nxt = job_params(job0 + (int)tk);
+                drawing = have_next;
+                pending = false;
+            }
+            unsigned tk_mine = 0xFFFFFFFFu;
+            const bool draw = drawing && ch + 1 == nch;
+            if (draw && tid == 0) {
+                if (ctr) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(tk_mine) : "v"((uint64_t)(uintptr_t)ctr), "v"(1u) : "memory");
+                else tk_mine = (unsigned)(kfirst + (kstat++) * kstep);
+            }
             const bool same = ch + 1 < nch;
             const Src nx = step_src(same ? cur : nxt, same ? ch + 1 : 0, same || have_next);
             const int nb_ = par ^ 1;
@@ -259,6 +299,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
 #undef RDP
 #undef ROW1
 #undef ROW2
+            if (draw && tid < 64) {                    // wave 0: the ticket is older than the step's 9 DMA pieces
+                if (tid == 0) {
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    asm volatile("ds_write_b32 %0, %1 offset:8" :: "v"(sched_a), "v"(tk_mine) : "memory");
+                }
+            }
             par ^= 1;
         }
 
@@ -295,15 +341,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
             pend = true;
         }
         if (!have_next) break;
-        job = njob;
         cur = nxt;
+        pending = drawing;                            // whether a job follows `cur` is known behind its first barrier
+        have_next = false;
     }
+    leave();
 }
 
 bool conv3x3d_applies(const Conv3Args& a) {
     const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2, w_bytes = (size_t)((a.N + 127) / 128) * 128 * 9 * a.C * 2;
     return unetrir_cfg().conv3x3d && !a.colstat && (a.H & 1) == 0 && (a.W & 1) == 0 && (a.H / 2) % DTR == 0 && (a.W / 2) % DTC == 0 &&
-           a.C >= 16 && a.C % 16 == 0 && a.N >= 32 && a.N % 32 == 0 && a.N <= DMAXN && a.ldi >= a.C && (a.ldi & 7) == 0 &&
+           a.C >= 32 && a.C % 16 == 0 && a.N >= 32 && a.N % 32 == 0 && a.N <= DMAXN && a.ldi >= a.C && (a.ldi & 7) == 0 &&
            (a.ldo & 7) == 0 && (!a.addend || (a.ldadd & 7) == 0) && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
 }
 
@@ -311,6 +359,6 @@ int launch_conv3x3d_bf16(const Conv3Args& a, hipStream_t s) {
     const long long jobs = (long long)a.B * (a.H / 2 / DTR) * (a.W / 2 / DTC) * ((a.N + DNB - 1) / DNB);
     const int cus = 256;
     const int grid = (int)(jobs < cus ? jobs : cus);
-    hipLaunchKernelGGL(conv3x3d_bf16_kernel, dim3((unsigned)grid), dim3(512), 0, s, a, (int)jobs, UNETRIR_ABL_HOST());
+    hipLaunchKernelGGL(conv3x3d_bf16_kernel, dim3((unsigned)grid), dim3(512), 0, s, a, (int)jobs, sched_slot(s), UNETRIR_ABL_HOST());
     return (int)hipGetLastError();
 }

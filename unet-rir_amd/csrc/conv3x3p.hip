@@ -170,7 +170,8 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
         float* red = reinterpret_cast<float*>(smem + PRED);
         if (tid == 0) {                                   // the first two tickets
             unsigned* tk = reinterpret_cast<unsigned*>(smem + PSCHED);
-            tk[0] = take(); tk[1] = take();
+            if (ctr) { const unsigned t = __hip_atomic_fetch_add(ctr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tk[0] = t; tk[1] = t + 1; }   // one round trip
+            else { tk[0] = take(); tk[1] = take(); }
         }
         (void)red;
         if (tid < 128) reinterpret_cast<float*>(smem + PBIAS)[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(512) void upconv3x3q_bf16_kernel(const Conv3Args a,
     if (tid < QBN) reinterpret_cast<float*>(smem + QBIAS)[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.f;
     if (tid == 0) {                                       // the first two tickets
         unsigned* tk = reinterpret_cast<unsigned*>(smem + QSCHED);
-        tk[0] = take(); tk[1] = take();
+        if (ctr) { const unsigned t = __hip_atomic_fetch_add(ctr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tk[0] = t; tk[1] = t + 1; }   // one round trip
+        else { tk[0] = take(); tk[1] = take(); }
     }
     __syncthreads();
     const unsigned tk0 = reinterpret_cast<const unsigned*>(smem + QSCHED)[0], tk1 = reinterpret_cast<const unsigned*>(smem + QSCHED)[1];
