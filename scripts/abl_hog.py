@@ -59,3 +59,15 @@ for (Cc, N, HW) in ((64, 128, 256), (128, 256, 128)):
             t0, t1 = timed(fn, False), timed(fn, True)
             print(f"{Cc}<->{N}@{HW} {name} {'on ' if on else 'off'}: alone {t0:7.1f} us, beside {n_hog} x {lds} B workgroups {t1:7.1f} us ({t1/t0:.2f}x)", flush=True)
         ops.set_config(**{sw: 1})
+
+
+# the 64 -> 64 strip kernel (fixed assignment of column strips) against conv3x3h
+x = ops.Act((torch.rand((B, 256, 256, 64), device=dev) - 0.5).to(dt))
+w = ((torch.rand((64, 9, 64), device=dev) - 0.5) * 0.1).to(dt)
+y = ops.Act(torch.empty((B, 256, 256, 64), device=dev, dtype=dt))
+g = ops.geom(B, 256, 256, 64, 64, 3, 1)
+fn = lambda: ops.conv2d_fwd(g, x, w, None, y)
+for on in (1, 0):
+    ops.set_config(conv3x3s=on)
+    t0, t1 = timed(fn, False), timed(fn, True)
+    print(f"64->64@256 conv3x3s {'on ' if on else 'off'}: alone {t0:7.1f} us, beside {n_hog} x {lds} B workgroups {t1:7.1f} us ({t1/t0:.2f}x)", flush=True)
