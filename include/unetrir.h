@@ -17,9 +17,12 @@
  *     produces; unetrir_transpose_weight_f32 makes the other one;
  *   - Cin and Cout multiples of 4 unless stated; TF padding='same' geometry;
  *   - asynchronous on `stream`, never allocate, never synchronise; thread-safe for
- *     distinct streams.  The library holds exactly two pieces of process-global state,
- *     both off the data path and documented where they are declared: the kernel-selection
- *     switches (unetrir_config) and the profiling brackets (unetrir_prof_*);
+ *     distinct streams.  The library holds three pieces of process-global state, documented
+ *     where they are declared: the kernel-selection switches (unetrir_config), the profiling
+ *     brackets (unetrir_prof_*), and the tile-ticket slots of the persistent convolution
+ *     kernels - a static device array of counters, one slot per stream that has launched
+ *     such a kernel (at most 128 streams; beyond that the kernels fall back to a fixed tile
+ *     assignment), zero between launches; no memory is allocated for it;
  *   - return 0 on success, a hipError_t value or UNETRIR_EINVAL otherwise.
  */
 #ifndef UNETRIR_H
