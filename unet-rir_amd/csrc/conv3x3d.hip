@@ -88,6 +88,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
         job0 = 0; cnt = njobs; kfirst = blockIdx.x; kstep = gridDim.x;
     }
     int kstat = 0;
+    // ticket -> job of the range.  Consecutive jobs are the channel tiles of one pixel tile and should run at the same time on
+    // different CUs (they share the patch in L2), but a workgroup draws its first two tickets at once: within a round of 64 tickets
+    // even tickets walk through the first 32 jobs and odd ones through the second 32
+    auto job_of = [&](unsigned t) -> int {
+        if (!ctr) return job0 + (int)t;
+        const unsigned r = t >> 6, i = t & 63;
+        return job0 + (int)((r * 64 + 63 < (unsigned)cnt) ? r * 64 + (i >> 1) + (i & 1) * 32 : t);
+    };
 
     // ---- bias of all output channels, once
     {
@@ -207,9 +215,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
     __bf16* __restrict__ out = (__bf16*)a.out;
     const __bf16* __restrict__ addend = (const __bf16*)a.addend;
 
-    Job cur = job_params(job0 + (int)tk0);
+    Job cur = job_params(job_of(tk0));
     bool have_next = tk1 < (unsigned)cnt;           // a next job is known to exist
-    Job nxt = have_next ? job_params(job0 + (int)tk1) : cur;
+    Job nxt = have_next ? job_params(job_of(tk1)) : cur;
     bool pending = false;                             // the next job's ticket is on its way (drawn in the last job's last step)
     bool drawing = have_next;                         // tickets are drawn until the first one past the end
     {
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3d_bf16_kernel(const Conv3Args a
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
                 have_next = tk < (unsigned)cnt;
-                if (have_next) nxt = job_params(job0 + (int)tk);
+                if (have_next) nxt = job_params(job_of(tk));
                 drawing = have_next;
                 pending = false;
             }
