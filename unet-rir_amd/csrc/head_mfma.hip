@@ -283,28 +283,31 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
 // One MFMA tile is [16 channels] x [16 pixels], K = 32 = two vertical taps x 16 (n,kw) slots (12 used); three K steps
 // cover the six vertical taps.  The weight fragments (12) stay in registers; the dy rows are expanded once into their
 // 32-byte-per-pixel (n,kw) images in a 6-slot LDS ring, read conflict-free by ds_read_b128.  A workgroup (4 waves x 64
-// pixels, C = 64) walks 32 output rows; results leave through an LDS row image as 16-byte NHWC stores (the kernel is
-// bound by writing dx).
+// pixels, C = 64) walks HD_ROWS output rows.  The kernel is bound by writing dx (268 MB at configs[1]): the channels of the
+// MFMA rows are permuted (tile ct, row r <-> channel 32 (ct >> 1) + 8 (r >> 2) + 4 (ct & 1) + (r & 3)) so that a lane's
+// accumulators of tiles (2m, 2m + 1) are 8 consecutive channels - 16-byte NHWC stores straight from the registers, no LDS
+// row image and no barrier for it; 50 KB of LDS and 16-row blocks put two to three workgroups on a CU (round 1: one 32-row
+// workgroup per CU with 4 barriers per row, 104 us).
 // ------------------------------------------------------------------------------------------------------------------
-#define HD_OL 72              // output row image: pixel stride in elements (144 B)
+#define HD_ROWS 16            // output rows per workgroup
 
 __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __restrict__ dy, int lddy, int B, int H, int W,
                                                               const float* __restrict__ w, __bf16* __restrict__ dx, int lddx) {
     constexpr int C = 64;
     __shared__ __attribute__((aligned(16))) __bf16 Dq[6][256 * 16];        // 49152 B
-    __shared__ __attribute__((aligned(16))) __bf16 Os[256 * HD_OL];        // 36864 B
     __shared__ __attribute__((aligned(16))) __bf16 dyrow[2][272];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int nrb = (H + HM_ROWS - 1) / HM_ROWS;
+    const int nrb = (H + HD_ROWS - 1) / HD_ROWS;
     const int img = blockIdx.x / nrb, rb = blockIdx.x - img * nrb;
-    const int y0 = rb * HM_ROWS;
-    const int nrows = (H - y0) < HM_ROWS ? (H - y0) : HM_ROWS;
+    const int y0 = rb * HD_ROWS;
+    const int nrows = (H - y0) < HD_ROWS ? (H - y0) : HD_ROWS;
     const __bf16* di = dy + (size_t)img * H * W * lddy;
 
     for (int i = tid; i < 2 * 272; i += 256) (&dyrow[0][0])[i] = (__bf16)0.f;
 
-    // weight fragments (A operand): row = channel ct*16 + l15, k = 8*lq + j <-> vertical tap 2*kp + (lq>>1), slot 8*(lq&1) + j
+    // weight fragments (A operand): row l15 of tile ct = channel 32 (ct >> 1) + 8 (l15 >> 2) + 4 (ct & 1) + (l15 & 3), k = 8*lq + j <->
+    // vertical tap 2*kp + (lq>>1), slot 8*(lq&1) + j
     bf16x8 wf[3][4];
 #pragma unroll
     for (int kp = 0; kp < 3; ++kp)
@@ -318,19 +321,20 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
                 float f = 0.f;
                 if (idx < 12) {
                     const int n = idx / 6, kw = idx - n * 6;
-                    f = w[(size_t)(n * 36 + kh * 6 + kw) * C + ct * 16 + l15];
+                    f = w[(size_t)(n * 36 + kh * 6 + kw) * C + 32 * (ct >> 1) + 8 * (l15 >> 2) + 4 * (ct & 1) + (l15 & 3)];
                 }
                 v[j] = (__bf16)f;
             }
             wf[kp][ct] = v;
         }
 
-    // expand dy row r into ring slot r mod 6 (all threads; two barriers inside)
-    auto push_row = [&](int r) {
+    // expand dy row r into ring slot r mod 6 (all threads).  `guard`: a barrier in front of the staging write - needed when the
+    // previous expansion's reads of the staging row are not already behind a barrier (back-to-back calls in the prologue)
+    auto push_row = [&](int r, bool guard) {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
         if ((unsigned)r < (unsigned)H && tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)r * W + tid) * lddy);
-        __syncthreads();
+        if (guard) __syncthreads();
         dyrow[0][tid + 3] = d[0]; dyrow[1][tid + 3] = d[1];
         __syncthreads();
         bf16x8 lo, hi;
@@ -344,11 +348,11 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
         *reinterpret_cast<bf16x8*>(dst) = lo;
         *reinterpret_cast<bf16x8*>(dst + 8) = hi;
     };
-    for (int r = y0 - 3; r < y0 + 2; ++r) push_row(r);
+    for (int r = y0 - 3; r < y0 + 2; ++r) push_row(r, true);
 
     for (int yy = 0; yy < nrows; ++yy) {
         const int yo = y0 + yy;
-        push_row(yo + 2);                             // the slot it replaces (row yo - 4) was last read one step ago, two barriers back
+        push_row(yo + 2, false);                      // the slot it replaces (row yo - 4) was last read one step ago, behind the barrier inside
         __syncthreads();
         f32x4 acc[4][4];
 #pragma unroll
@@ -371,21 +375,18 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
                 for (int ct = 0; ct < 4; ++ct) acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[kp][ct], fb, acc[t][ct], 0, 0, 0);
             }
         }
-        // acc[t][ct][j] = dx[yo][q = wave*64 + 16t + l15][c = ct*16 + 4*lq + j]
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                bf16x4 o;
-                o[0] = (__bf16)acc[t][ct][0]; o[1] = (__bf16)acc[t][ct][1]; o[2] = (__bf16)acc[t][ct][2]; o[3] = (__bf16)acc[t][ct][3];
-                *reinterpret_cast<bf16x4*>(Os + (wave * 64 + 16 * t + l15) * HD_OL + ct * 16 + 4 * lq) = o;
-            }
-        __syncthreads();
+        // acc[t][2m + u][j] = dx[yo][q = wave*64 + 16t + l15][c = 32 m + 8 lq + 4 u + j]: 16 bytes per lane and (t, m)
         __bf16* orow = dx + ((size_t)img * H + yo) * W * lddx;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int q = (tid >> 3) + 32 * j, g = tid & 7;
-            if (q < W) *reinterpret_cast<uint4*>(orow + (size_t)q * lddx + g * 8) = *reinterpret_cast<const uint4*>(Os + q * HD_OL + g * 8);
+        for (int t = 0; t < 4; ++t) {
+            const int q = wave * 64 + 16 * t + l15;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[t][2 * m + (e >> 2)][e & 3];
+                if (q < W) *reinterpret_cast<bf16x8*>(orow + (size_t)q * lddx + 32 * m + 8 * lq) = o;
+            }
         }
     }
 }
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
 bool head_dgrad_mfma_applies(int W, int C) { return W <= 256 && C == 64; }
 
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s) {
-    const unsigned grid = (unsigned)(B * ((H + HM_ROWS - 1) / HM_ROWS));
+    const unsigned grid = (unsigned)(B * ((H + HD_ROWS - 1) / HD_ROWS));
     hipLaunchKernelGGL(head_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, s, (const __bf16*)dy, lddy, B, H, W, w, (__bf16*)dx, lddx);
     return (int)hipGetLastError();
 }
