@@ -61,8 +61,15 @@ constexpr int GSMEM = 2 * GP_BYTES + 3 * GW_BYTES;   // 153600
 // 18 x 18 patches are stacked in LDS (36 rows of 18 pixels), so the second 16-pixel half of a fragment row is the other
 // image, one constant offset away, and nothing else in the pipeline changes - full tiles where the 32-column tile would be
 // half empty.
-template <int VAR, bool PAIR = false>
+// BN = 64 (paired tiles only): a workgroup owns 64 output channels and its eight waves 2 tile rows each - twice the workgroups
+// where 128-channel tiles leave half of the CUs without one (1024 -> 1024 at 16 x 16, batch 32: 128 tiles)
+template <int VAR, bool PAIR = false, int BN = GBN>
 __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
+    constexpr int RPW = BN == 128 ? 4 : 2;                 // tile rows per wave
+    constexpr int WB = 3 * BN * 64;                        // one kernel tile: [3 vertical taps][BN channels][32 input channels]
+    constexpr int W_INSTR = WB / 1024;                     // 24 / 12 wave-instructions
+    constexpr int WPW = (W_INSTR + 7) / 8;                 // 3 / 2 per wave
+    static_assert(BN == 128 || (BN == 64 && PAIR && (VAR & 2)), "64-channel tiles exist for the paired 16x16x32 body");
     constexpr int PC = PAIR ? 18 : GPC;                    // patch columns
     constexpr int NPX = PAIR ? 36 * 18 : GNPX;             // patch pixels
     constexpr int P_INSTR = (NPX + 15) / 16;               // 41 / 39 wave-instructions
@@ -70,20 +77,20 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     constexpr int P_PER_WAVE = (P_INSTR + 7) / 8;
     constexpr int RP = PC * 64;                            // patch row pitch, bytes
     constexpr int HO = PAIR ? 18 * RP : 1024;              // second half of a fragment row: the other image / 16 columns on
-    constexpr int SMEM = 2 * P_BYTES + 3 * GW_BYTES;       // 157696 / 153600
+    constexpr int SMEM = 2 * P_BYTES + 3 * WB;             // 157696 / 153600 (BN = 64: 120832)
     static_assert(!PAIR || (VAR & 2), "the paired tile exists for the 16x16x32 body only");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const __bf16* __restrict__ w = (const __bf16*)a.w;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
     const int l31 = lane & 31, hi = lane >> 5;
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr bool S16 = (VAR & 2) != 0;              // v_mfma_f32_16x16x32_bf16 body
 
     const int tiles_x = PAIR ? 1 : (a.W + 31) / 32, tiles_y = (a.H + GTR - 1) / GTR;
-    const int ntN = (a.N + GBN - 1) / GBN;
+    const int ntN = (a.N + BN - 1) / BN;
     int id = blockIdx.x;
     if ((gridDim.x & 7) == 0) id = (id & 7) * (gridDim.x >> 3) + (id >> 3);   // neighbouring tiles on one XCD (shared L2)
     const int nt = id % ntN; id /= ntN;
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     const int img = id / tiles_y;                          // PAIR: index of the image pair
     const int img0 = PAIR ? 2 * img : img;
     const int nimg = PAIR ? (a.B - img0 < 2 ? a.B - img0 : 2) : 1;
-    const int y0 = ty * GTR, x0 = tx * 32, n0 = nt * GBN;
+    const int y0 = ty * GTR, x0 = tx * 32, n0 = nt * BN;
     const int C = a.C;
     const int nch = C / 32;
     const int ldw = 9 * C;
@@ -120,12 +127,17 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
         const bool ok = p < NPX && im < nimg && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         pa[j] = ok ? (uint32_t)((((im * a.H + iy) * a.W + ix) * a.ldi + gs * 8) * 2) : OOB;
     }
-    uint32_t wp[GW_PER_WAVE];
+    uint32_t wp[3];                                   // (fixed bounds: see pa / pi above)
+    int wi[3];
+    static_assert(WPW <= 3, "kernel-tile instructions per wave");
     const int dxs = ((a.flip & 1) ? -C : C) * 2;        // weight-tap step per dx, bytes
 #pragma unroll
-    for (int j = 0; j < GW_PER_WAVE; ++j) {
-        const int row = 16 * (wave + 8 * j) + sub;     // dy * 128 + local channel
-        const int dy = row >> 7, nl = row & 127;
+    for (int j = 0; j < WPW; ++j) {
+        int i = wave + 8 * j;
+        if (i > W_INSTR - 1) i = W_INSTR - 1;          // (BN = 64: the last waves repeat the final instruction - uniform DMA counts)
+        wi[j] = i;
+        const int row = 16 * i + sub;                  // dy * BN + local channel
+        const int dy = row / BN, nl = row % BN;
         const int gs = S16 ? slot ^ ((nl & 4) >> 1) : slot ^ ((nl >> 2) & 3);
         const int n = n0 + nl;
         const int tap0 = (a.flip & 1) ? 8 - 3 * dy : 3 * dy;
@@ -139,18 +151,18 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lptr_t)(dst + pi[j] * 1024), 16, pa[j] + c0b, 0, 0, 0);
     };
     auto issue_w = [&](int ch, int dx, int buf) {
-        unsigned char* dst = smem + 2 * P_BYTES + buf * GW_BYTES;
+        unsigned char* dst = smem + 2 * P_BYTES + buf * WB;
         const uint32_t off = ch * 64 + dx * dxs;
 #pragma unroll
-        for (int j = 0; j < GW_PER_WAVE; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + (wave + 8 * j) * 1024), 16, wp[j] + off, 0, 0, 0);
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + wi[j] * 1024), 16, wp[j] + off, 0, 0, 0);
     };
 
     f32x16 acc[S16 ? 1 : 4][S16 ? 1 : 2];             // 32x32x16 body: [image row][32-channel tile]
-    f32x4 acc16[S16 ? 4 : 1][2][4];                   // 16x16x32 body: [image row][16-pixel half][16-channel tile]
+    f32x4 acc16[S16 ? RPW : 1][2][4];                 // 16x16x32 body: [image row][16-pixel half][16-channel tile]
     if constexpr (S16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -168,14 +180,14 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     issue_p(0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (WPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     // fragment addresses: weights  row (dy*128 + wn*64 + j*32 + l31) * 64 + ((kk*2+hi)*16 ^ swz(l31))
     //                     patch    ((4*wm + r) * 34 + l31 + dx) * 64 + ((kk*2+hi)*16 ^ swz(l31 + dx))
-    const uint32_t b_lane = lds0 + 2 * P_BYTES + (wn * 64 + l31) * 64;
+    const uint32_t b_lane = lds0 + 2 * P_BYTES + (wn * 64 + l31) * 64;      // (32x32x16 body: BN = 128 only)
     const uint32_t b_swz = (l31 & 12) << 2;
     const uint32_t a_lane = lds0 + (4 * wm * PC + l31) * 64;
 
@@ -195,22 +207,23 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             }
             const uint32_t a_dx = a_chunk + dx * 64;
             const uint32_t a_swz = ((l31 + dx) & 12) << 2;
-            const uint32_t b_buf = b_lane + dx * GW_BYTES;
-            const uint32_t b_buf16 = lds0 + 2 * P_BYTES + dx * GW_BYTES + (wn * 64 + l15) * 64;
+            const uint32_t b_buf = b_lane + dx * WB;
+            const uint32_t b_buf16 = lds0 + 2 * P_BYTES + dx * WB + (wn * 64 + l15) * 64;
             if constexpr (S16) {
                 // one pass over the 32-channel chunk: lane (l15, lq) reads granule lq of row l15 (weights: channel, patch: pixel)
                 const uint32_t ba = b_buf16 + ((lq << 4) ^ ((l15 & 4) << 3));
-                const uint32_t aa = lds0 + (ch & 1) * P_BYTES + (4 * wm * PC + l15 + dx) * 64 + ((lq << 4) ^ (((l15 + dx) & 4) << 3));
+                const uint32_t aa = lds0 + (ch & 1) * P_BYTES + (RPW * wm * PC + l15 + dx) * 64 + ((lq << 4) ^ (((l15 + dx) & 4) << 3));
                 u32x4 wf[3][4], pf[6][2];
-#define RDW(dy) DSR128(wf[dy][0], ba, dy * 8192 + 0); DSR128(wf[dy][1], ba, dy * 8192 + 1024); \
-                DSR128(wf[dy][2], ba, dy * 8192 + 2048); DSR128(wf[dy][3], ba, dy * 8192 + 3072)
+#define RDW(dy) DSR128(wf[dy][0], ba, dy * (BN * 64) + 0); DSR128(wf[dy][1], ba, dy * (BN * 64) + 1024); \
+                DSR128(wf[dy][2], ba, dy * (BN * 64) + 2048); DSR128(wf[dy][3], ba, dy * (BN * 64) + 3072)
 #define RDP(r) DSR128(pf[r][0], aa, r * RP + 0); DSR128(pf[r][1], aa, r * RP + HO)
 #define ROWS16(r)                                                                              \
     _Pragma("unroll") for (int dy = 0; dy < 3; ++dy) {                                         \
-        if (r - dy < 0 || r - dy > 3) continue;                                                \
+        if (r - dy < 0 || r - dy > RPW - 1) continue;                                          \
         _Pragma("unroll") for (int h = 0; h < 2; ++h)                                          \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) MMA16(acc16[r - dy][h][t], wf[dy][t], pf[r][h]); \
     }
+                if constexpr (RPW == 4) {
                 RDW(0); RDP(0); RDW(1); RDP(1); RDW(2); RDP(2);          // 18 reads in flight
                 __builtin_amdgcn_s_setprio(1);
                 LGKM_WAIT(12); ROWS16(0);
@@ -222,6 +235,14 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
                 LGKM_WAIT(4); ROWS16(3);
                 LGKM_WAIT(2); ROWS16(4);
                 LGKM_WAIT(0); ROWS16(5);
+                } else {                                                 // two tile rows: patch rows 0..3
+                RDW(0); RDP(0); RDW(1); RDP(1); RDW(2); RDP(2); RDP(3);  // 20 reads in flight
+                __builtin_amdgcn_s_setprio(1);
+                LGKM_WAIT(14); ROWS16(0);
+                LGKM_WAIT(8); ROWS16(1);
+                LGKM_WAIT(2); ROWS16(2);
+                LGKM_WAIT(0); ROWS16(3);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
 #undef RDW
@@ -272,16 +293,24 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
             }
             // ---- retire what the next step reads; younger DMAs stay in flight across the barrier
             if constexpr (!(VAR & 8)) {
+            // (counts: a kernel tile is WPW = 3 or 2 instructions per wave, a patch P_PER_WAVE = 5 or 6)
+#define VM_WP() do { if constexpr (P_PER_WAVE + WPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+                     else if constexpr (P_PER_WAVE + WPW == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); \
+                     else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); } while (0)
+#define VM_W() do { if constexpr (WPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } while (0)
+            static_assert(P_PER_WAVE + WPW >= 7 && P_PER_WAVE + WPW <= 9, "vmcnt immediates");
             if (dx == 0) {
-                if (more) { if constexpr (P_PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }   // W(s+2) + P(ch+1) may remain
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");        // W(s+2) may remain
+                if (more) VM_WP();                                            // W(s+2) + P(ch+1) may remain
+                else VM_W();                                                  // W(s+2) may remain
             } else if (dx == 1) {
-                if (more) { if constexpr (P_PER_WAVE == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }   // P(ch+1) + W(s+2) may remain
+                if (more) VM_WP();                                            // P(ch+1) + W(s+2) may remain
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
-                if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // W(s+2) may remain; P(ch+1) is older: retired
+                if (more) VM_W();                                             // W(s+2) may remain; P(ch+1) is older: retired
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+#undef VM_WP
+#undef VM_W
             }
             if constexpr (!(VAR & 4)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -300,7 +329,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs_s[e] = 0.f; cs_q[e] = 0.f; }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < RPW / 2; ++half) {
         if (half) WAVE_LDS_FENCE();
         if constexpr (S16) {
             // acc16[i][h][t][e] = D[n = 16t + 4*lq + e][pixel column = 16h + l15] of image row y0 + 4*wm + i
@@ -346,7 +375,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int p = ps * 8 + pl;
-            const int y = y0 + 4 * wm + 2 * half + (p >> 5), x = PAIR ? (p & 15) : x0 + (p & 31);
+            const int y = y0 + RPW * wm + 2 * half + (p >> 5), x = PAIR ? (p & 15) : x0 + (p & 31);
             const int imo = PAIR ? img0 + ((p >> 4) & 1) : img;          // PAIR: the second 16-pixel half is the second image
             if (y >= a.H || x >= a.W || nq >= a.N || imo >= a.B) continue;
             uint4 v = *reinterpret_cast<const uint4*>(stage + p * GSROW + cq * 16);
@@ -377,15 +406,17 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
         if (lane < 8) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                red[((wm * 128) + wn * 64 + lane * 8 + e) * 2 + 0] = cs_s[e];
-                red[((wm * 128) + wn * 64 + lane * 8 + e) * 2 + 1] = cs_q[e];
+                red[((wm * BN) + wn * 64 + lane * 8 + e) * 2 + 0] = cs_s[e];
+                red[((wm * BN) + wn * 64 + lane * 8 + e) * 2 + 1] = cs_q[e];
             }
         }
         __syncthreads();
-        if (tid < 256) {
+        if (tid < 2 * BN) {
             const int ch = tid >> 1, st = tid & 1;
-            const float t = ((red[(0 * 128 + ch) * 2 + st] + red[(1 * 128 + ch) * 2 + st]) + red[(2 * 128 + ch) * 2 + st]) +
-                            red[(3 * 128 + ch) * 2 + st];
+            float t = ((red[(0 * BN + ch) * 2 + st] + red[(1 * BN + ch) * 2 + st]) + red[(2 * BN + ch) * 2 + st]) +
+                      red[(3 * BN + ch) * 2 + st];
+            if constexpr (BN == 64)            // eight row groups
+                t = (((t + red[(4 * BN + ch) * 2 + st]) + red[(5 * BN + ch) * 2 + st]) + red[(6 * BN + ch) * 2 + st]) + red[(7 * BN + ch) * 2 + st];
             const size_t row = ((size_t)img * tiles_y + ty) * tiles_x + tx;
             if (n0 + ch < a.N) a.colstat[(row * a.N + n0 + ch) * 2 + st] = t;
         }
@@ -417,7 +448,12 @@ long long conv3x3g_colstat_rows(const Conv3Args& a) {
 
 int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
     if (conv3x3g_pair_applies(a)) {
-        const long long tiles = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR) * ((a.N + GBN - 1) / GBN);
+        const long long ptiles = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR);
+        const long long tiles = ptiles * ((a.N + GBN - 1) / GBN);
+        if (tiles < 256 && (a.N & 63) == 0) {             // half of the CUs would stay empty: 64-channel tiles, twice the workgroups
+            hipLaunchKernelGGL((conv3x3g_bf16_kernel<2, true, 64>), dim3((unsigned)(ptiles * (a.N / 64))), dim3(512), 0, s, a);
+            return (int)hipGetLastError();
+        }
         hipLaunchKernelGGL((conv3x3g_bf16_kernel<2, true>), dim3((unsigned)tiles), dim3(512), 0, s, a);
         return (int)hipGetLastError();
     }
