@@ -59,5 +59,24 @@ for (B, H, Ci, Co) in [(8, 128, 64, 128), (8, 64, 128, 256)]:          # stride-
     dw = torch.empty((Co, 9, Ci), device=dev)
     ws = ops.Workspace(dev)
     total += screen(f"conv s2 wgrad {Ci}->{Co} @{H}", lambda: ops.conv2d_wgrad(g, x, y, dw, ws), dw)
+# the persistent kernels at their launched sizes (batch 32: >= 512 / 1024 tiles; tiles drawn at run time, counted waits across tile
+# boundaries): conv3x3p forward / data gradient, conv3x3d (strided forward, plain kernel copy), upconv3x3q (transposed forward)
+for (B, HW, Ci, Co) in [(32, 128, 128, 128), (32, 64, 256, 256)]:
+    g = ops.geom(B, HW, HW, Ci, Co, 3, 1)
+    x, y = ops.Act(rnd((B, HW, HW, Ci))), ops.Act(rnd((B, HW, HW, Co)))
+    wh, wt = rnd((Co, 9, Ci), 0.1), rnd((Ci, 9, Co), 0.1)
+    out = ops.Act(torch.empty((B, HW, HW, Co), dtype=torch.bfloat16, device=dev))
+    dx = ops.Act(torch.empty((B, HW, HW, Ci), dtype=torch.bfloat16, device=dev))
+    assert ops.conv3x3_kernel(g, 0, x) == "conv3x3p"
+    total += screen(f"conv3x3p fwd  {Ci}->{Co} @{HW} B={B}", lambda: ops.conv2d_fwd(g, x, wh, None, out), out.base)
+    total += screen(f"conv3x3p dgrad {Ci}->{Co} @{HW} B={B}", lambda: ops.conv2d_dgrad(g, y, wt, dx), dx.base)
+for (B, H, Ci, Co) in [(32, 256, 64, 128), (32, 128, 128, 256)]:
+    g = ops.geom(B, H, H, Ci, Co, 3, 2)
+    x = ops.Act(rnd((B, H, H, Ci)))
+    wh, wt = rnd((Co, 9, Ci), 0.1), rnd((Ci, 9, Co), 0.1)
+    out = ops.Act(torch.empty((B, H // 2, H // 2, Co), dtype=torch.bfloat16, device=dev))
+    total += screen(f"conv3x3d fwd {Ci}->{Co} @{H}->{H//2} B={B}", lambda: ops.conv2d_fwd(g, x, wh, None, out), out.base)
+    dx = ops.Act(torch.empty((B, H, H, Ci), dtype=torch.bfloat16, device=dev))
+    total += screen(f"upconv3x3q dgrad {Co}->{Ci} @{H//2}->{H} B={B}", lambda: ops.conv2d_dgrad(g, out, wt, dx), dx.base)
 print("race screen:", "clean" if total == 0 else f"{total} failures")
 sys.exit(1 if total else 0)
