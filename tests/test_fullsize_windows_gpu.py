@@ -154,7 +154,7 @@ def test_conv3x3_forward_and_data_gradient_windows(U, Ci, Co, HW, ld):
         _check(tot[:, 1], (yd * yd).sum(dim=(0, 1, 2)).cpu(), "colstat sum of squares", 1e-5)
 
 
-@pytest.mark.parametrize("Ci,Co,HW", [(64, 128, 256), (128, 256, 128)])
+@pytest.mark.parametrize("Ci,Co,HW", [(64, 128, 256), (128, 256, 128), (512, 1024, 32)])     # the last: 16 x 16 output, conv3x3d's narrow tiles
 def test_strided_conv_windows(U, Ci, Co, HW):
     """enc2.down / enc3.down (dl_models/u_net.py:269-276): forward (conv3x3d, plain and packed kernel copy), data gradient with the
     in-place skip-gradient addend (upconv3x3q)."""

@@ -325,6 +325,7 @@ BF16_CONV_CASES = [
     # tiles, the last one 32 wide / 9 jobs (grid not a multiple of 8) / 272 jobs on 256 workgroups (two jobs per workgroup)
     (1, 16, 64, 16, 32, 3, 2), (2, 32, 128, 48, 96, 3, 2), (2, 32, 64, 32, 288, 3, 2), (9, 16, 64, 32, 128, 3, 2), (34, 64, 128, 32, 64, 3, 2),
     (2, 32, 64, 128, 192, 3, 2),                                      # ... with the packed kernel copy: two channel tiles, the second half empty
+    (2, 32, 32, 32, 64, 3, 2), (3, 64, 96, 48, 96, 3, 2), (2, 32, 32, 64, 128, 3, 2),   # outputs 16 / 48 wide: the tap-table kernel keeps them (a 16 x 16-tile variant of conv3x3d measured slower: 131 vs 111 us)
     (2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1),            # LDS-DMA kernel (conv3x3g): ragged tiles / channels, 3 chunks
     (3, 16, 16, 64, 160, 3, 1), (4, 16, 16, 96, 128, 3, 1), (2, 32, 16, 64, 128, 3, 1), (5, 9, 11, 32, 72, 3, 1),   # conv3x3g, two narrow images per tile (odd batch, ragged)
     (2, 32, 32, 128, 256, 3, 1),                                      # LDS-DMA kernel: forward 4 chunks, data gradient 8 chunks
@@ -395,7 +396,8 @@ def test_conv2d_bf16(U, case, monkeypatch):
 @pytest.mark.parametrize("case", [(2, 6, 5, 16, 8, 3), (1, 4, 4, 64, 32, 3), (2, 3, 3, 128, 64, 3), (2, 12, 40, 48, 72, 3),
                                   (1, 16, 32, 136, 64, 3),
                                   (1, 16, 64, 96, 72, 3), (2, 20, 32, 32, 64, 3),    # LDS-DMA kernel (upconv3x3g): 3 chunks / ragged N, ragged rows
-                                  (2, 8, 32, 64, 32, 3), (1, 16, 32, 128, 48, 3)])   # data gradient on conv3x3d (input in a concat buffer)
+                                  (2, 8, 32, 64, 32, 3), (1, 16, 32, 128, 48, 3),    # data gradient on conv3x3d (input in a concat buffer)
+                                  (2, 16, 16, 64, 32, 3)])                           # 16-wide adjoint: tap-table kernel
 def test_conv2d_transpose_bf16(U, case):
     ops = U.ops
     B, H, W, Ci, Co, k = case
