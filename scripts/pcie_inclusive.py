@@ -22,7 +22,7 @@ def batches():
 
 
 t0 = None
-for i, (spec_in, emb, spec_out) in enumerate(U.DeviceBatchPipeline(batches(), dev, nhwc=True, stream=(eng.opt_stream if os.environ.get('PIPE_OPT_STREAM', '1') == '1' else None))):
+for i, (spec_in, emb, spec_out) in enumerate(U.DeviceBatchPipeline(batches(), dev, nhwc=True, stream=(eng.opt_stream if os.environ.get('PIPE_OPT_STREAM', '0') == '1' else None))):
     if i == 10:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     tr.step(spec_in, emb, spec_out)

@@ -18,13 +18,15 @@ import torch
 class DeviceBatchPipeline:
     """for spec_in, emb, spec_out in DeviceBatchPipeline(generator, device): trainer.step(spec_in, emb, spec_out)
 
-    depth = batches staged ahead.  The copy stream can share a hardware queue with a compute stream, in which case a copy
-    completes only after the kernels queued before it; with 2 batches ahead the producer then waits for its staging slots and
-    the step time doubles (29.9 ms at cfg 2); with 6 the host-fed step is 15.7-20 ms against 13.8 ms device-resident."""
+    depth = batches staged ahead.  The copy stream carries host -> device copies only (the NHWC -> NCHW permutation runs on the
+    consumer's stream): a kernel on it can land on a hardware queue behind the step's compute kernels and hold every copy behind
+    it up (round 1: 15.7-20 ms host-fed against 13.8 device-resident, 29.9 with two batches ahead).  Measured at cfg 2
+    (scripts/pcie_inclusive.py): 14.2 ms host-fed against 13.0 ms device-resident.  Do not pass a stream that also runs kernels
+    (the optimizer stream: 30.7 ms)."""
 
     def __init__(self, source, device, depth=6, nhwc=True, stream=None):
         self.source, self.device, self.depth, self.nhwc = source, torch.device(device), max(1, depth), nhwc
-        self.stream = stream        # copy stream; pass one the engine has probed as concurrent (e.g. engine.opt_stream) to keep copies off the compute queues
+        self.stream = stream        # copy stream (default: a stream of its own); it must not run kernels
 
     def _to_pinned(self, a, slot, k):
         t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a.contiguous()
@@ -50,17 +52,11 @@ class DeviceBatchPipeline:
                         slot_ev[s].synchronize()               # HERE, in the producer: the training thread never blocks on a copy)
                     host = [self._to_pinned(spec_in, slots[s], "in"), self._to_pinned(emb, slots[s], "emb"),
                             self._to_pinned(spec_out, slots[s], "out")]
-                    with torch.cuda.stream(stream):
-                        dev = [h.to(self.device, non_blocking=True) for h in host]
-                        copied = torch.cuda.Event()
-                        copied.record(stream)
-                        slot_ev[s] = copied
-                        if self.nhwc:                          # [B,H,W,2] -> contiguous [B,2,H,W]
-                            dev[0] = dev[0].permute(0, 3, 1, 2).contiguous()
-                            dev[2] = dev[2].permute(0, 3, 1, 2).contiguous()
-                        dev[0], dev[2] = dev[0].float(), dev[2].float()
-                        ev = torch.cuda.Event()
+                    with torch.cuda.stream(stream):            # the copy stream carries NOTHING but host -> device copies (DMA engines):
+                        dev = [h.to(self.device, non_blocking=True) for h in host]     # a kernel on it can land on a hardware queue
+                        ev = torch.cuda.Event()                # behind the step's compute kernels and hold the copies behind it up
                         ev.record(stream)
+                        slot_ev[s] = ev
                     q.put((dev, ev))
                 q.put(stop)
             except BaseException as e:                         # surface generator errors in the consumer
@@ -79,7 +75,10 @@ class DeviceBatchPipeline:
             cur.wait_event(ev)                                 # a wait in the stream; the host keeps running ahead
             for t in dev:
                 t.record_stream(cur)
-            yield dev[0], dev[1], dev[2]
+            if self.nhwc:                                      # [B,H,W,2] -> contiguous [B,2,H,W], on the consumer's stream (two 17 MB
+                dev[0] = dev[0].permute(0, 3, 1, 2).contiguous()     # passes, ~10 us each at cfg 2)
+                dev[2] = dev[2].permute(0, 3, 1, 2).contiguous()
+            yield dev[0].float(), dev[1], dev[2].float()
         th.join()
 
 
