@@ -389,6 +389,13 @@ int unetrir_dropout_mask_f32(float* mask, long long n, float p, unsigned long lo
                              unetrir_stream_t stream);
 int unetrir_index_to_i32(const void* idx, int elem_bytes, long long n, int* out, unetrir_stream_t stream);
 
+/* ---- input staging for a host-fed train step (DataGenerator.__getitem__, datageneratorv2.py:64-102, hands over host arrays):
+ *      for k < n: memcpy src[k] -> pinned[k] (page-locked staging owned by the caller), then an asynchronous host -> device copy
+ *      pinned[k] -> dev[k] on `stream`.  One call per batch from the producer thread: the foreign call runs without the
+ *      interpreter lock, so staging a batch does not hold the lock the thread that launches the step takes ~300 times per step. */
+int unetrir_stage_h2d(int n, const void* const* src, void* const* pinned, void* const* dev, const size_t* bytes,
+                      unetrir_stream_t stream);
+
 /* ---- profiling hooks used by bench.py: when enabled every conv launch is bracketed by HIP
  *      events on its own stream; collect() synchronises those events and returns, per kernel
  *      family, launch count, total milliseconds and total algorithmic FLOPs.  Process-global

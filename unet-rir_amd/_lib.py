@@ -126,6 +126,7 @@ _SIGS = {
                                            C.c_int, c_stream]),
     "unetrir_head6x6_wgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                              c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_stage_h2d": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), c_stream]),
     "unetrir_conv2d_colstat_rows_bf16": (C.c_longlong, [C.POINTER(ConvGeom), C.c_int, C.c_int]),
     "unetrir_conv3x3_kernel_id_bf16": (C.c_int, [C.POINTER(ConvGeom), C.c_int, C.c_int]),
     "unetrir_conv2d_fwd_colstat_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,

@@ -1,6 +1,7 @@
 // api.hip - the C ABI (include/unetrir.h): TF padding='same' geometry -> tap tables -> launches.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 #include "kernels.h"
@@ -579,6 +580,18 @@ int unetrir_dense_dgrad_f32(const float* dy, int lddy, const float* w, float* dx
 int unetrir_transpose_weight_f32(const float* w, float* wt, int N, int T, int C, unetrir_stream_t stream) {
     if (!w || !wt || N <= 0 || T <= 0 || C <= 0) return UNETRIR_EINVAL;
     return launch_transpose_weight(w, wt, N, T, C, (hipStream_t)stream);
+}
+
+int unetrir_stage_h2d(int n, const void* const* src, void* const* pinned, void* const* dev, const size_t* bytes,
+                      unetrir_stream_t stream) {
+    if (n <= 0 || !src || !pinned || !dev || !bytes) return UNETRIR_EINVAL;
+    for (int k = 0; k < n; ++k) {
+        if (!src[k] || !pinned[k] || !dev[k]) return UNETRIR_EINVAL;
+        std::memcpy(pinned[k], src[k], bytes[k]);
+        const hipError_t e = hipMemcpyAsync(dev[k], pinned[k], bytes[k], hipMemcpyHostToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
 }
 
 int unetrir_prof_enable(int on) {

@@ -14,27 +14,30 @@ import threading
 import numpy as np
 import torch
 
+from . import ops
+
 
 class DeviceBatchPipeline:
     """for spec_in, emb, spec_out in DeviceBatchPipeline(generator, device): trainer.step(spec_in, emb, spec_out)
 
     depth = batches staged ahead.  The copy stream carries host -> device copies only (the NHWC -> NCHW permutation runs on the
     consumer's stream): a kernel on it can land on a hardware queue behind the step's compute kernels and hold every copy behind
-    it up (round 1: 15.7-20 ms host-fed against 13.8 device-resident, 29.9 with two batches ahead).  Measured at cfg 2
-    (scripts/pcie_inclusive.py): 14.2 ms host-fed against 13.0 ms device-resident.  Do not pass a stream that also runs kernels
+    it up (round 1: 15.7-20 ms host-fed against 13.8 device-resident, 29.9 with two batches ahead).  Staging a batch is one
+    foreign call without the interpreter lock.  Measured at cfg 2 (scripts/pcie_inclusive.py): 13.4 ms host-fed against 13.0 ms
+    device-resident.  Do not pass a stream that also runs kernels
     (the optimizer stream: 30.7 ms)."""
 
     def __init__(self, source, device, depth=6, nhwc=True, stream=None):
         self.source, self.device, self.depth, self.nhwc = source, torch.device(device), max(1, depth), nhwc
         self.stream = stream        # copy stream (default: a stream of its own); it must not run kernels
 
-    def _to_pinned(self, a, slot, k):
-        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a.contiguous()
+    def _pinned_like(self, a, slot, k):
+        shape = tuple(a.shape)
+        dtype = torch.from_numpy(a[:0] if a.ndim else a).dtype if isinstance(a, np.ndarray) else a.dtype
         buf = slot.get(k)
-        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
-            buf = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
+            buf = torch.empty(shape, dtype=dtype).pin_memory()
             slot[k] = buf
-        buf.copy_(t)
         return buf
 
     def __iter__(self):
@@ -50,11 +53,16 @@ class DeviceBatchPipeline:
                     s = i % len(slots)
                     if slot_ev[s] is not None:                 # the copies that last read this slot have finished (waited for
                         slot_ev[s].synchronize()               # HERE, in the producer: the training thread never blocks on a copy)
-                    host = [self._to_pinned(spec_in, slots[s], "in"), self._to_pinned(emb, slots[s], "emb"),
-                            self._to_pinned(spec_out, slots[s], "out")]
-                    with torch.cuda.stream(stream):            # the copy stream carries NOTHING but host -> device copies (DMA engines):
-                        dev = [h.to(self.device, non_blocking=True) for h in host]     # a kernel on it can land on a hardware queue
-                        ev = torch.cuda.Event()                # behind the step's compute kernels and hold the copies behind it up
+                    # the copy stream carries NOTHING but host -> device copies (DMA engines): a kernel on it can land on a hardware
+                    # queue behind the step's compute kernels and hold the copies behind it up.  Staging + copies of the three arrays
+                    # are ONE foreign call (ops.stage_h2d: memcpy into the pinned slot, hipMemcpyAsync), which runs without the
+                    # interpreter lock - the training thread needs that lock ~300 times per step.
+                    arrs = [np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a.contiguous() for a in (spec_in, emb, spec_out)]
+                    pinned = [self._pinned_like(a, slots[s], k) for a, k in zip(arrs, ("in", "emb", "out"))]
+                    with torch.cuda.stream(stream):
+                        dev = [torch.empty(p.shape, dtype=p.dtype, device=self.device) for p in pinned]
+                        ops.stage_h2d([a.ctypes.data if isinstance(a, np.ndarray) else a.data_ptr() for a in arrs], pinned, dev, stream)
+                        ev = torch.cuda.Event()
                         ev.record(stream)
                         slot_ev[s] = ev
                     q.put((dev, ev))

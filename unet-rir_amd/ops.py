@@ -246,6 +246,16 @@ def cast_weights_batched(table):
     check(_lib.lib().unetrir_cast_weights_batched_bf16(dev.data_ptr(), n, _stream()), "cast_weights_batched")
 
 
+def stage_h2d(src_ptrs, pinned, dev, stream):
+    """Host arrays (addresses src_ptrs) -> pinned staging tensors -> device tensors on `stream`, in one foreign call (no interpreter
+    lock while it copies).  src_ptrs[k] must stay alive until the call returns; pinned[k] until the copies have completed."""
+    n = len(src_ptrs)
+    vp, sz = C.c_void_p * n, C.c_size_t * n
+    nbytes = [p.numel() * p.element_size() for p in pinned]
+    check(_lib.lib().unetrir_stage_h2d(n, vp(*src_ptrs), vp(*[p.data_ptr() for p in pinned]), vp(*[d.data_ptr() for d in dev]),
+                                       sz(*nbytes), C.c_void_p(stream.cuda_stream)), "stage_h2d")
+
+
 def add_f32_to_bf16(a: Act, b: Act, y: Act):
     """y = a + b with a, y bf16 and b fp32, dense buffers (Add() of dl_models/u_net.py:229 in the bf16 trunk)."""
     check(_lib.lib().unetrir_add_f32_to_bf16(_p(a), _p(b), _p(y), a.base.numel(), _stream()), "add_f32_to_bf16")
