@@ -124,8 +124,21 @@ class Runner:
     def sync(self):
         torch.cuda.synchronize()
         if self.world > 1:
-            dist.barrier(device_ids=[self.device.index])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[self.device.index])
+            else:
+                dist.barrier()
             torch.cuda.synchronize()
+
+    def replicas_in_sync(self, theta):
+        """MirroredStrategy's invariant after the timed steps (outside the timed region): every replica holds bit-identical
+        variables - the SUM all-reduce and the optimizer ran on the same values everywhere.  Compared through two fp64
+        checksums (sum and sum of squares) gathered from all ranks."""
+        t = theta.double()
+        mine = torch.stack([t.sum(), (t * t).sum()])
+        allv = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(allv, mine)
+        return bool(all(torch.equal(v, allv[0]) for v in allv))
 
     def timed(self, step, steps, warmup, prof_level=0):
         """`warmup` untimed and EXACTLY `steps` timed calls of step(); barrier + synchronize on both sides, MAX over ranks."""
@@ -169,6 +182,8 @@ class Runner:
         dt, fam = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, level)
         res = {"value": batch * self.world * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup,
                "dtype": dtype, "loss": tr.last_loss(), "params": eng.n_params(), "fam": fam, "overlap": overlap}
+        if self.world > 1:
+            res["replicas_in_sync"] = self.replicas_in_sync(eng.theta)
         del tr, eng
         torch.cuda.empty_cache()
         return res
@@ -288,6 +303,10 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--force-dp", action="store_true", help="1-rank rehearsal of the bucketed RCCL all-reduce path")
     ap.add_argument("--eager-pg", action="store_true", help="create the RCCL communicator before the engine's streams (A/B)")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 rank path on a one-GPU box: every rank uses cuda:0 and the collectives go through "
+                         "gloo (RCCL refuses two ranks on one device).  Exercises the product step at world_size N with real kernels; "
+                         "the value it prints is not a scaling measurement and says so")
     ap.add_argument("--through-module", action="store_true",
                     help="headline value from the drop-in boundary (UNet module + Trainer.compute_loss) instead of Trainer.step")
     ap.add_argument("--lean", action="store_true", help="headline run only (no sub-runs, other configs or CPU baseline)")
@@ -305,7 +324,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU")
     n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if n_dev < world or local_rank >= n_dev:
+    if args.rehearse_shared_gpu:
+        local_rank = 0
+    if n_dev < (1 if args.rehearse_shared_gpu else world) or local_rank >= n_dev:
         raise SystemExit(f"bench.py rank {rank}: --gpus {world} needs {world} visible GPUs, this node shows {n_dev}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
@@ -319,7 +340,9 @@ def main():
         # RCCL's stream can share a queue with the main or the weight-gradient stream, and its event waits (a gradient bucket
         # waiting for the backward pass) then stall every kernel queued behind them: measured 15.0-15.3 instead of 13.9 ms per
         # step in about half of the runs (1-rank rehearsal, --force-dp); created afterwards it lands on a free queue.
-        if args.eager_pg:
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif args.eager_pg:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -377,6 +400,9 @@ def main():
                                + ("bf16 activations/gradients, fp32 accumulate/statistics/master weights" if head_dtype == "bf16"
                                   else "fp32 throughout"),
                    "global_batch": global_batch, "parallelism": f"dp{world}", "rccl_world_size": world if dist.is_initialized() else 1,
+                   **({"replicas_in_sync": eng_res["replicas_in_sync"]} if "replicas_in_sync" in eng_res else {}),
+                   **({"REHEARSAL": "all ranks share cuda:0, collectives over gloo: exercises the N-rank code path, NOT a scaling "
+                                    "measurement"} if args.rehearse_shared_gpu else {}),
                    "params": eng_res["params"],
                    "driven_by": ("UNet(nn.Module).model(...) + Trainer.compute_loss/apply_gradients" if args.through_module
                                  else "Trainer.step(UNetEngine)"),

@@ -36,3 +36,12 @@ def test_rank_environment_must_match_gpus():
 def test_single_gpu_path_refuses_to_run_without_a_gpu():
     r = _run(["--gpus", "1"])
     assert r.returncode != 0 and ("visible GPUs" in r.stderr or "MI355X" in r.stderr)
+
+
+def test_shared_gpu_rehearsal_also_refuses_to_run_without_a_gpu():
+    """--rehearse-shared-gpu (all ranks on cuda:0, collectives over gloo) relaxes the one-GPU-per-rank check, not the
+    need for a GPU: no CPU fallback of the product step."""
+    r = _run(["--gpus", "2", "--rehearse-shared-gpu", "--lean", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "visible GPUs" in r.stderr or "MI355X" in r.stderr
+    assert r.stdout.strip() == ""
