@@ -1,4 +1,4 @@
-"""wgrad3x3g timing ablations (ablation build; bits: 512 no XCD remap, 1 no DMA after the first patch, 2 no partial stores,
+"""wgrad3x3g timing ablations (ablation build; bits: 512 no XCD remap, 16 / 32 / 64 DMA placement 2-2-2-2-2 / 4-3-3 / all up front, 128 staggered quartets, 1 no DMA after the first patch, 2 no partial stores,
 4 no MFMA): python scripts/abl_wgrad.py "128,128,128;256,256,64;128,64,256" [modes, default 0,512] """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,5 +28,9 @@ for sh in sys.argv[1].split(";"):
             for _ in range(20): ops.conv2d_wgrad(g, x, dy, dw, ws)
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 20
+            if m == 0:
+                ref = dw.clone()
+            elif not (m & 7) and 'ref' in dir():      # variants that keep the arithmetic: bit-identical to the product kernel
+                assert torch.equal(dw, ref), f"abl={m}: result differs from abl=0 (max {float((dw - ref).abs().max())})"
             print(f"C={Cc} N={N} {HW}: abl={m:3d} {ms*1e3:7.1f} us {2.0*B*HW*HW*Cc*N*9/ms/1e9:6.0f} TF/s", flush=True)
 aset(0)

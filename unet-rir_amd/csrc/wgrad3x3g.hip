@@ -46,7 +46,7 @@ __device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
 // split-K reduction (75 MB written + read per launch with NH = 1).
 struct WgSrc { __amdgpu_buffer_rsrc_t rx, rd; int iy0, ix0, py0, px0, xbase, dbase, gv; };     // DMA sources of one patch
 
-template <int NH>
+template <int NH, int SCH = 1, int STAG = 0>
 __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a, int abl) {   // abl (ablation build only): 1 no DMA after the first patch, 2 no partial stores, 4 no MFMA
     __shared__ __attribute__((aligned(1024))) unsigned char smem_all[NH * 2 * WBUF];
     const int half = NH == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
@@ -193,6 +193,11 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
     }
     started = true;
     int k = 0;
+    // STAG: the second quartet (waves 4-7, the SIMD partners of waves 0-3) runs half a patch behind the first: two workgroup
+    // barriers per patch (before step 0 and before step 4); a quartet's patch boundary is every other one, the other's falls
+    // in the middle of its patch.  One quartet's barrier wait, first-rows read burst and DMA wait then sit beside the other's
+    // MFMA steps instead of beside the same bubble (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+    if (NH == 2 && STAG && half == 1) __builtin_amdgcn_s_barrier();
     for (int it = 0; it < n_it; ++it, k ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of patch g has landed ...
         __builtin_amdgcn_s_barrier();                            // ... everybody's has; everybody is done reading the other buffer
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         const WgSrc nx = patch_src(nxt_on ? g0 + it + 1 : g0 + it);
         const int nb_ = k ^ 1;
 #define PIECES(J0, J1) do { if (nxt_on) { piece(nx, nb_, J0); piece(nx, nb_, J1); } } while (0)
+#define MIDBAR() do { if (NH == 2 && STAG) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } } while (0)
         const uint32_t xb = lds0 + k * WBUF, db = xb + WX_BYTES;
         uint32_t xa[4];
 #pragma unroll
@@ -211,17 +217,47 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         RDX(xl[1][0], xh[1][0], 1, 0); RDX(xl[1][1], xh[1][1], 1, 1); RDX(xl[1][2], xh[1][2], 1, 2);
         RDX(xl[2][0], xh[2][0], 2, 0); RDX(xl[2][1], xh[2][1], 2, 1); RDX(xl[2][2], xh[2][2], 2, 2);
         RDD(d0l, d0h, 0);
+        // DMA placement: ten pieces per wave and patch.  SCH 1 (product): 3-3-2-2 behind the first four K steps - measured 1.5-4 %
+        // faster than 2-2-2-2-2 (SCH 0: the last pieces have 1 us less to land), 4-3-3 (SCH 2) and all ten up front (SCH 3: the
+        // issue burst stalls the matrix pipe); 0, 2, 3 and the staggered quartets (STAG: +2 %) are instantiated in the ablation build only
+        constexpr int sch = SCH;
+        if constexpr (sch == 0) {
         STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true); PIECES(0, 1);
         STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true); PIECES(2, 3);
         STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true); PIECES(4, 5);
         STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true); PIECES(6, 7);
-        STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true); PIECES(8, 9);
+        MIDBAR(); STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true); PIECES(8, 9);
         STEP(5, 2, 0, 1, d1l, d1h, d0l, d0h, true);
+        } else if constexpr (sch == 1) {       // 3-3-2-2
+        STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true); PIECES(0, 1); if (nxt_on) piece(nx, nb_, 2);
+        STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true); PIECES(3, 4); if (nxt_on) piece(nx, nb_, 5);
+        STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true); PIECES(6, 7);
+        STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true); PIECES(8, 9);
+        MIDBAR(); STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true);
+        STEP(5, 2, 0, 1, d1l, d1h, d0l, d0h, true);
+        } else if constexpr (sch == 2) {       // 4-3-3
+        STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true); PIECES(0, 1); PIECES(2, 3);
+        STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true); PIECES(4, 5); if (nxt_on) piece(nx, nb_, 6);
+        STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true); PIECES(7, 8); if (nxt_on) piece(nx, nb_, 9);
+        STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true);
+        MIDBAR(); STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true);
+        STEP(5, 2, 0, 1, d1l, d1h, d0l, d0h, true);
+        } else {                     // all ten before the first step
+        PIECES(0, 1); PIECES(2, 3); PIECES(4, 5); PIECES(6, 7); PIECES(8, 9);
+        STEP(0, 0, 1, 2, d0l, d0h, d1l, d1h, true);
+        STEP(1, 1, 2, 0, d1l, d1h, d0l, d0h, true);
+        STEP(2, 2, 0, 1, d0l, d0h, d1l, d1h, true);
+        STEP(3, 0, 1, 2, d1l, d1h, d0l, d0h, true);
+        MIDBAR(); STEP(4, 1, 2, 0, d0l, d0h, d1l, d1h, true);
+        STEP(5, 2, 0, 1, d1l, d1h, d0l, d0h, true);
+        }
         STEP(6, 0, 1, 2, d0l, d0h, d1l, d1h, true);
         // last step: x row 10 does not exist; nothing left to prefetch
         STEP(7, 1, 2, 0, d1l, d1h, d0l, d0h, false);
     }
+    if (NH == 2 && STAG && half == 0) __builtin_amdgcn_s_barrier();
 #undef STEP
+#undef MIDBAR
 #undef PIECES
 #undef MM
 #undef RDD
@@ -287,6 +323,13 @@ int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, v
     a.patches_per_split = per;
     const unsigned tiles = (unsigned)(((a.N + 63) / 64) * ((a.C + 63) / 64));
     a.xcd_remap = (tiles > 1 && ns % 8 == 0 && !UNETRIR_ABL(UNETRIR_ABL_HOST(), 512)) ? 1 : 0;
+#ifdef UNETRIR_ABLATIONS
+    if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 16)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 0>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
+    else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 32)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 2>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
+    else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 64)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 3>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
+    else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 128)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 1, 1>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
+    else
+#endif
     if (nh == 2) hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<2>, dim3(tiles, ns), dim3(512), 0, s, a, UNETRIR_ABL_HOST());
     else hipLaunchKernelGGL(wgrad3x3g_bf16_kernel<1>, dim3(tiles, ns), dim3(256), 0, s, a, UNETRIR_ABL_HOST());
     const int err = (int)hipGetLastError();
