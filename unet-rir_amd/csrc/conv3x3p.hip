@@ -63,10 +63,22 @@ constexpr uint32_t OOB = 0xF0000000u;
 struct Tile { int img, y0, x0, n0, pix; };
 }  // namespace
 
-// abl (ablation build only): 1 no patch DMA, 8 no kernel DMA (after the prologue), 2 no output stores, 4 no MFMA loop
+#ifdef UNETRIR_ABLATIONS
+// in-kernel clock stamps (ablation build, bit 2048): per workgroup (shader-clock ticks, 100 MHz ticks) over the whole persistent
+// loop; they go to this array only, no output depends on them (MI355X_MICROARCH.md, DVFS give-back item 6)
+__device__ unsigned long long g_stamps_conv3x3p[256][2];
+extern "C" int unetrir_abl_stamps_conv3x3p(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_conv3x3p), (size_t)n * 16);
+}
+#endif
+// abl (ablation build only): 1 no patch DMA, 8 no kernel DMA (after the prologue), 2 no output stores, 4 no MFMA loop, 2048 clock stamps
 __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, int pix_tiles, int per_xcd, unsigned* sched, int abl) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[PSMEM];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
+#ifdef UNETRIR_ABLATIONS
+    unsigned long long st0 = 0, sr0 = 0;
+    if (UNETRIR_ABL(abl, 2048)) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -432,6 +444,12 @@ __global__ __launch_bounds__(512) void conv3x3p_bf16_kernel(const Conv3Args a, i
         __syncthreads();
         flush_row(cs_pending, cs_par ^ 1);
     }
+#ifdef UNETRIR_ABLATIONS
+    if (UNETRIR_ABL(abl, 2048) && tid == 0) {
+        g_stamps_conv3x3p[blockIdx.x & 255][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_stamps_conv3x3p[blockIdx.x & 255][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    }
+#endif
     // ---- the last workgroup to leave clears the launch's counters for the next launch on this stream (every workgroup has
     //      drawn its last - failing - ticket before it counts itself out)
     if (sched && tid == 0) {

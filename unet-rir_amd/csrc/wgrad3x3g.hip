@@ -44,9 +44,17 @@ __device__ __forceinline__ bf16x8 frag(const u32x2& lo, const u32x2& hi) {
 // raw barrier is workgroup wide) and at the end the second quartet hands its 144 accumulators per lane to the first through
 // the then idle 160 KB of LDS.  Same occupancy, half as many partial slabs: half the fp32 partial traffic and half the
 // split-K reduction (75 MB written + read per launch with NH = 1).
+#ifdef UNETRIR_ABLATIONS
+// in-kernel clock stamps (ablation build, bit 2048): per workgroup (shader-clock ticks, 100 MHz ticks) around the K loop; they go
+// to this array only, no output depends on them (MI355X_MICROARCH.md, DVFS give-back item 6)
+__device__ unsigned long long g_stamps_wgrad3x3g[1024][2];
+extern "C" int unetrir_abl_stamps_wgrad3x3g(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps_wgrad3x3g), (size_t)n * 16);
+}
+#endif
 struct WgSrc { __amdgpu_buffer_rsrc_t rx, rd; int iy0, ix0, py0, px0, xbase, dbase, gv; };     // DMA sources of one patch
 
-template <int NH, int SCH = 1, int STAG = 0>
+template <int NH, int SCH = 1, int STAG = 0, int FAKE16 = 0>
 __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kernel(const Wgrad3ArgsH a, int abl) {   // abl (ablation build only): 1 no DMA after the first patch, 2 no partial stores, 4 no MFMA
     __shared__ __attribute__((aligned(1024))) unsigned char smem_all[NH * 2 * WBUF];
     const int half = NH == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
@@ -169,7 +177,14 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
 #define RDX(lo, hi, R, KW) do { TRR(lo, xa[(KW) & 3], (R) * (WXW * 128) + (KW) * 128); \
                                 TRR(hi, xa[((KW) + 4) & 3], (R) * (WXW * 128) + ((KW) + 4) * 128); } while (0)
 #define RDD(lo, hi, R) do { TRR(lo, da, (R) * (WTPW * 128)); TRR(hi, da, (R) * (WTPW * 128) + 4 * 128); } while (0)
-#define MM(T_, A_, B_) do { if (!UNETRIR_ABL(abl, 4)) acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[T_], 0, 0, 0); } while (0)
+    // FAKE16 (ablation build, WRONG RESULTS): the flops of one 32x32x16 issued as two 16x16x32 on the same operand registers - what
+    // the matrix-instruction shape alone does to the time and to the clock the chip holds
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+#define MM(T_, A_, B_) do { if (!UNETRIR_ABL(abl, 4)) { if constexpr (FAKE16) { \
+        f32x4_ lo_, hi_; _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { lo_[e_] = acc[T_][e_]; hi_[e_] = acc[T_][4 + e_]; } \
+        lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, lo_, 0, 0, 0); hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, hi_, 0, 0, 0); \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { acc[T_][e_] = lo_[e_]; acc[T_][4 + e_] = hi_[e_]; } \
+    } else acc[T_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_, acc[T_], 0, 0, 0); } } while (0)
     // one K step: dy row R against x rows R (kh 0), R+1, R+2.  S0 = ring slot of x row R (refilled with row R+3 once the
     // kh = 0 products are issued), S1, S2 = slots of rows R+1, R+2.
 #define STEP(R, S0, S1, S2, DC_LO, DC_HI, DN_LO, DN_HI, MORE)                                                     \
@@ -186,6 +201,10 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         MM(6, fd, frag(xl[S2][0], xh[S2][0])); MM(7, fd, frag(xl[S2][1], xh[S2][1])); MM(8, fd, frag(xl[S2][2], xh[S2][2])); \
     } while (0)
 
+#ifdef UNETRIR_ABLATIONS
+    unsigned long long st0 = 0, sr0 = 0;
+    if (UNETRIR_ABL(abl, 2048)) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     if (n_it > 0) {
         const WgSrc s0 = patch_src(g0);
 #pragma unroll
@@ -256,6 +275,13 @@ __global__ __launch_bounds__(256 * NH, NH == 1 ? 2 : 1) void wgrad3x3g_bf16_kern
         STEP(7, 1, 2, 0, d1l, d1h, d0l, d0h, false);
     }
     if (NH == 2 && STAG && half == 0) __builtin_amdgcn_s_barrier();
+#ifdef UNETRIR_ABLATIONS
+    if (UNETRIR_ABL(abl, 2048) && threadIdx.x == 0) {
+        const int w = (blockIdx.y * gridDim.x + blockIdx.x) & 1023;
+        g_stamps_wgrad3x3g[w][0] = __builtin_amdgcn_s_memtime() - st0;
+        g_stamps_wgrad3x3g[w][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+    }
+#endif
 #undef STEP
 #undef MIDBAR
 #undef PIECES
@@ -327,6 +353,7 @@ int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, v
     if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 16)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 0>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
     else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 32)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 2>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
     else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 64)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 3>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
+    else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 4096)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 1, 0, 1>), dim3(tiles, ns), dim3(512), 0, s, a, UNETRIR_ABL_HOST() & 2048);
     else if (nh == 2 && UNETRIR_ABL(UNETRIR_ABL_HOST(), 128)) hipLaunchKernelGGL((wgrad3x3g_bf16_kernel<2, 1, 1>), dim3(tiles, ns), dim3(512), 0, s, a, 0);
     else
 #endif
