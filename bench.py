@@ -221,12 +221,12 @@ class Runner:
         batch 32 of [2,256,256], through its boundary class and the Trainer."""
         U = self.U
         model = U.ResAE((256, 256, 2), (2, 16), (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 16 * 64, name="resae",
-                        batch_size=32, device=self.device, dtype=dtype)
+                        batch_size=32, device=self.device, dtype=dtype, overlap=True)
         tr = U.Trainer(model, lr=5e-7, alpha=0.9)
         spec_in, emb, spec_out = synthetic_batch(32, 256, 256, self.device, 1234)
         dt, _ = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, 0)
         res = {"workload": "BASELINE.json configs[4]: ResAE filters (32,64,128,256), k 3, s 2, latent 32, n_neurons 1024, batch 32 of "
-                           "[2,256,256], full train step, " + ("bf16 storage of the convolutional trunk" if dtype == "bf16" else "fp32 storage"),
+                           "[2,256,256], full train step, " + ("bf16 storage of the convolutional trunk" if dtype == "bf16" else "fp32 storage") + ", side-stream weight gradients",
                "value": 32 * steps / dt, "unit": "spectrograms/s",
                "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "params": model.engine.n_params(), "dtype": dtype}
         del tr, model

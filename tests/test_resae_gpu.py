@@ -70,3 +70,43 @@ def test_resae_param_count_cfg5(U):
     """main_training.py:132-141 configuration at 256x256: ~17.2 M parameters."""
     cfg = RA.ResAEConfig(256, 256)
     assert sum(int(np.prod(s)) for s in RA.param_shapes(cfg).values()) == 17_173_922
+
+
+@pytest.mark.parametrize("kind,dtype", [("resae", "bf16"), ("resae", "f32"), ("unet3", "bf16"), ("ae", "f32")])
+def test_graph_engine_side_stream_schedule_is_bit_identical(U, kind, dtype):
+    """overlap_wgrad=True (weight gradients on a side stream, buckets handed over from it, Adam bucket by bucket on a third)
+    runs the SAME launches in another order across streams: three Trainer steps give bit-identical parameters, moving
+    statistics and loss as the single-stream schedule (the race screen of the schedule itself is tests/test_schedule_sim.py)."""
+    H = W = 64
+    B = 4
+
+    def build(overlap):
+        if kind == "resae":
+            eng = U.ResAEEngine(H, W, B, (8, 16, 32, 64), (3, 3, 3, 3), (2, 2, 2, 2), 32, 64, device=DEV, dtype=dtype, overlap_wgrad=overlap)
+        elif kind == "ae":
+            eng = U.AutoencoderEngine(H, W, B, (8, 16, 32, 64), (3, 3, 3, 3), (2, 2, 2, 2), 32, 64, device=DEV, dtype=dtype, overlap_wgrad=overlap)
+        else:
+            eng = U.UNetGraphEngine(H, W, B, F0=8, k=3, mode=3, device=DEV, dtype=dtype, overlap_wgrad=overlap)
+        g = torch.Generator(); g.manual_seed(3)
+        eng.reset_parameters(g)
+        eng.dropout_seed = 77
+        return eng, U.Trainer(eng, lr=1e-3, bucket_bytes=16 << 10)
+
+    gen = torch.Generator(); gen.manual_seed(5)
+    spec_in = torch.rand((B, 2, H, W), generator=gen).to(DEV)
+    spec_out = torch.rand((B, 2, H, W), generator=gen).to(DEV)
+    emb = torch.randint(26, 1282, (B, 2, 16), generator=gen).to(DEV)
+    res = []
+    for overlap in (False, True):
+        eng, tr = build(overlap)
+        assert (eng.wg_stream is not None) == overlap
+        if overlap:
+            assert tr.adam_stream is not None and len(tr.bucketer.bounds) > 3
+        losses = [tr.step(spec_in, emb, spec_out, return_loss=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, eng.theta.clone(), eng.adam_m.clone(), {k: v.clone() for k, v in eng.moving.items()}))
+    (l0, t0, m0, mv0), (l1, t1, m1, mv1) = res
+    assert l0 == l1
+    assert torch.equal(t0, t1) and torch.equal(m0, m1)
+    for k in mv0:
+        assert torch.equal(mv0[k], mv1[k]), k

@@ -76,13 +76,13 @@ def _build(rt, B, overlap, world=1, bucket_bytes=32 << 20, kind="unet", **kw):
     if kind == "unet":
         eng = U.UNetEngine(H, W, B, F0=F0, k=3, device="cpu", runtime=rt, overlap_wgrad=overlap, n_replicas=world, **kw)
     elif kind == "graph3":
-        eng = U.UNetGraphEngine(H, W, B, F0=F0, k=3, mode=3, device="cpu", runtime=rt, n_replicas=world)
+        eng = U.UNetGraphEngine(H, W, B, F0=F0, k=3, mode=3, device="cpu", runtime=rt, n_replicas=world, overlap_wgrad=overlap)
     elif kind == "ae":
         eng = U.AutoencoderEngine(H, W, B, cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim, cfg.n_neurons,
-                                  device="cpu", runtime=rt, n_replicas=world)
+                                  device="cpu", runtime=rt, n_replicas=world, overlap_wgrad=overlap)
     else:
         eng = U.ResAEEngine(H, W, B, cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim, cfg.n_neurons,
-                            device="cpu", runtime=rt, n_replicas=world)
+                            device="cpu", runtime=rt, n_replicas=world, overlap_wgrad=overlap)
     eng.load_keras_params(params)
     tr = U.Trainer(eng, lr=1e-3, dropout=False, world_size=world, bucket_bytes=bucket_bytes)
     return R.Config(H, W), eng, tr
@@ -102,7 +102,8 @@ def _check_params(eng, want):
         assert err <= P_ATOL, (n, err)
 
 
-@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae"), (False, "ae")])
+@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae"), (False, "ae"),
+                                          (True, "graph3"), (True, "resae"), (True, "ae")])
 def test_full_step_on_the_product_schedule_matches_oracle(monkeypatch, overlap, kind):
     import cpu_ops
     from sim_runtime import SimRuntime
@@ -131,15 +132,16 @@ def test_full_step_on_the_product_schedule_matches_oracle(monkeypatch, overlap, 
         assert rt.n_cross_stream == 0
 
 
-def test_race_check_detects_a_missing_event_wait(monkeypatch):
-    """Negative control: take the 'side stream waits for the main stream' edge out of the schedule."""
+@pytest.mark.parametrize("kind", ["unet", "resae"])
+def test_race_check_detects_a_missing_event_wait(monkeypatch, kind):
+    """Negative control: take the 'side stream waits for the main stream' edge out of the schedule (hand schedule and graph engine)."""
     import cpu_ops
     from sim_runtime import RaceError, SimRuntime
     from oracle import torch_ref as R
     import unet_rir_amd.engine as E
     rt = SimRuntime()
     cpu_ops.install(monkeypatch, rt)
-    cfg, eng, tr = _build(rt, 2, True)
+    cfg, eng, tr = _build(rt, 2, True, kind=kind)
     spec_in, emb, spec_out = R.synthetic_batch(cfg, 2)
     monkeypatch.setattr(rt, "wait", lambda stream, ev: None if stream is eng.wg_stream else stream.merge(ev.clock))
     with pytest.raises(RaceError):
@@ -195,7 +197,8 @@ def _dp_worker(rank, world, port, out_path, overlap, kind):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae"), (False, "ae")])
+@pytest.mark.parametrize("overlap,kind", [(False, "unet"), (True, "unet"), (False, "graph3"), (False, "resae"), (False, "ae"),
+                                          (True, "resae"), (True, "graph3")])
 def test_two_rank_trainer_step_equals_single_process_oracle(tmp_path, overlap, kind):
     world = 2
     out = str(tmp_path / "dp")

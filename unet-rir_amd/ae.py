@@ -15,8 +15,8 @@ class AutoencoderEngine(GraphEngine):
 
     def __init__(self, H, W, B, conv_filters=(64, 128, 256, 512), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
                  latent_space_dim=64, n_neurons=2048, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None,
-                 share=None, dtype="f32"):
-        super().__init__(B, device, n_replicas, runtime, share, dtype)
+                 share=None, dtype="f32", overlap_wgrad=False):
+        super().__init__(B, device, n_replicas, runtime, share, dtype, overlap_wgrad)
         self.H, self.W = H, W
         self.filters, self.kernels, self.strides = tuple(conv_filters), tuple(conv_kernels), tuple(conv_strides)
         if any(f % 4 for f in self.filters) or any(s not in (1, 2) for s in self.strides):

@@ -110,6 +110,7 @@ class _SideStream:
 
 class UNetEngine:
     """One replica of the model for a fixed per-replica batch size B on one device."""
+    mask_on_side_stream = True       # the dropout mask's only consumers (information-vector branch) run on the side stream
 
     def __init__(self, H, W, B, F0=32, k=3, depth=4, batchnorm=True, inf_vector_shape=(2, 16), s0=1, s=2,
                  device="cuda:0", n_replicas=1, dtype="f32", overlap_wgrad=False, runtime=None, share=None,

@@ -254,8 +254,6 @@ class UNet(_EngineModule):
             raise ValueError("mode must be 0..3 (dl_models/u_net.py:280-287)")
         if self.res_factor != [2, 2] or self.resize_factor_0 != [1, 1]:
             raise NotImplementedError("only res_factor=[2,2], resize_factor_0=[1,1] are implemented")
-        if mode != 0 and overlap:
-            raise NotImplementedError("feature-block modes 1-3 run on the graph engine (single stream)")
         shp = tuple(input_shape)
         if len(shp) != 3 or 2 not in (shp[0], shp[2]):
             raise ValueError("input_shape must be (H, W, 2) or (2, H, W)")
@@ -280,7 +278,8 @@ class UNet(_EngineModule):
                               share=share)
         return UNetGraphEngine(self.H, self.W, B, F0=self.number_filters_0, k=self.kernels, depth=self.depth, mode=self.mode,
                                batchnorm=self.BatchNorm, inf_vector_shape=self.inf_vector_shape, device=self._device,
-                               n_replicas=self.n_replicas, runtime=self._rt, share=share, dtype=self.dtype_name)
+                               n_replicas=self.n_replicas, runtime=self._rt, share=share, dtype=self.dtype_name,
+                               overlap_wgrad=self.overlap)
 
     # `parameters.pkl` holds the reference's list (u_net.py:180-187) followed by the arguments it forgets (kernels, depth, and
     # this build's dtype) - `UNet.load` of the reference feeds BatchNorm into the `kernels` slot because of that omission.
@@ -331,9 +330,10 @@ class _AEFamily(_EngineModule):
     ENGINE = None
 
     def __init__(self, input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
-                 name, batch_size=None, device="cuda:0", n_replicas=1, dropout=True, fold_l2=True, runtime=None, dtype="f32"):
+                 name, batch_size=None, device="cuda:0", n_replicas=1, dropout=True, fold_l2=True, runtime=None, dtype="f32",
+                 overlap=False):
         super().__init__(device, batch_size, n_replicas, dropout, fold_l2, runtime)
-        self.dtype_name = dtype
+        self.dtype_name, self.overlap = dtype, overlap
         shp = tuple(input_shape)
         if len(shp) != 3 or 2 not in (shp[0], shp[2]):
             raise ValueError("input_shape must be (H, W, 2) or (2, H, W)")
@@ -349,7 +349,7 @@ class _AEFamily(_EngineModule):
     def _new_engine(self, B, share):
         return self.ENGINE(self.H, self.W, B, self.conv_filters, self.conv_kernels, self.conv_strides, self.latent_space_dim,
                            self.n_neurons, self.inf_vector_shape, device=self._device, n_replicas=self.n_replicas,
-                           runtime=self._rt, share=share, dtype=self.dtype_name)
+                           runtime=self._rt, share=share, dtype=self.dtype_name, overlap_wgrad=self.overlap)
 
     @property
     def encoder(self):
@@ -375,7 +375,7 @@ class _AEFamily(_EngineModule):
 class Autoencoder(_AEFamily):
     """Convolutional autoencoder of the reference (dl_models/autoencoder.py:34-62; main_training.py:118-129 builds it with
     filters (64,128,256,512), kernels 3, strides 2, latent 64, n_neurons 2048).  Constructor arguments keep the reference's
-    names and order; ``batch_size``, ``device``, ``n_replicas``, ``dropout``, ``fold_l2``, ``dtype`` are additions."""
+    names and order; ``batch_size``, ``device``, ``n_replicas``, ``dropout``, ``fold_l2``, ``dtype``, ``overlap`` are additions."""
     ENGINE = AutoencoderEngine
 
     def __init__(self, input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,
@@ -388,7 +388,7 @@ class ResAE(_AEFamily):
     """Residual autoencoder of the reference (dl_models/res_ae.py:35-70; main_training.py:130-140 builds it with filters
     (32,64,128,256), kernels 3, strides 2, latent 32, n_neurons 1024 - BASELINE.json configs[4]).  Constructor arguments keep
     the reference's names and order; ``batch_size``, ``device``, ``n_replicas``, ``dropout``, ``fold_l2``, ``dtype`` ("f32" /
-    "bf16" storage of the convolutional trunk) are additions."""
+    "bf16" storage of the convolutional trunk), ``overlap`` (weight gradients on a side stream, bucket-wise Adam on a third) are additions."""
     ENGINE = ResAEEngine
 
     def __init__(self, input_shape, inf_vector_shape, conv_filters, conv_kernels, conv_strides, latent_space_dim, n_neurons,

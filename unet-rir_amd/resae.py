@@ -15,8 +15,9 @@ class ResAEEngine(GraphEngine):
     """One replica of ResAE for a fixed per-replica batch size (constructor mirrors dl_models/res_ae.py:41-50)."""
 
     def __init__(self, H, W, B, conv_filters=(32, 64, 128, 256), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
-                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None, share=None, dtype="f32"):
-        super().__init__(B, device, n_replicas, runtime, share, dtype)
+                 latent_space_dim=32, n_neurons=1024, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None, share=None, dtype="f32",
+                 overlap_wgrad=False):
+        super().__init__(B, device, n_replicas, runtime, share, dtype, overlap_wgrad)
         self.H, self.W = H, W
         self.filters, self.kernels, self.strides = tuple(conv_filters), tuple(conv_kernels), tuple(conv_strides)
         if any(f % 4 for f in self.filters) or any(s not in (1, 2) for s in self.strides):

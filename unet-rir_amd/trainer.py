@@ -199,7 +199,7 @@ class Trainer:
 
     def _make_mask(self):
         eng = self.engine
-        side = getattr(eng, "wg_stream", None)
+        side = getattr(eng, "wg_stream", None) if getattr(eng, "mask_on_side_stream", False) else None
         if side is not None:       # its only consumers (the information-vector branch, forward and backward) run on that stream
             with self.rt.on(side):
                 return eng.make_dropout_mask()

@@ -15,8 +15,8 @@ from .engine import VEC_CH, EMB_DIM
 
 class UNetGraphEngine(GraphEngine):
     def __init__(self, H, W, B, F0=32, k=3, depth=4, mode=0, batchnorm=True, inf_vector_shape=(2, 16), device="cuda:0",
-                 n_replicas=1, runtime=None, share=None, dtype="f32"):
-        super().__init__(B, device, n_replicas, runtime, share, dtype)
+                 n_replicas=1, runtime=None, share=None, dtype="f32", overlap_wgrad=False):
+        super().__init__(B, device, n_replicas, runtime, share, dtype, overlap_wgrad)
         if mode not in (0, 1, 2, 3):
             raise ValueError("mode must be 0..3")
         if F0 % self.PAD:
