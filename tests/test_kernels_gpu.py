@@ -462,11 +462,13 @@ def test_batchnorm_bf16(U, shape):
     close(cs, gy.sum(dim=(0, 2, 3)), 1e-5, "bf16 colsum")
 
 
-@pytest.mark.parametrize("B,H,W,Cc", [(2, 20, 37, 32), (1, 70, 200, 64), (1, 33, 256, 128), (1, 12, 300, 64), (2, 9, 20, 16)])
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 20, 37, 32), (1, 70, 200, 64), (1, 33, 256, 128), (1, 12, 300, 64), (2, 9, 20, 16),
+                                      (1, 19, 512, 128), (2, 35, 523, 64), (1, 7, 257, 32)])
 def test_head_and_loss_bf16(U, B, H, W, Cc):
-    """Head forward / sigmoid+loss / head weight gradient on bf16 activations.  The matrix-core head (W <= 256, C in
-    {32,64,128}) takes the kernel as bf16, so the oracle runs on the bf16-rounded kernel; the last two shapes take the
-    direct kernels (fp32 kernel values: the rounded kernel is exactly representable there too)."""
+    """Head forward / sigmoid+loss / head weight gradient on bf16 activations.  The matrix-core head (C in {32,64,128}; images
+    wider than 256 pixels run in column blocks: 300, 512 = configs[3]'s width, 523 and 257 exercise the block seams) takes the
+    kernel as bf16, so the oracle runs on the bf16-rounded kernel; C = 16 takes the direct kernels (fp32 kernel values: the
+    rounded kernel is exactly representable there too)."""
     ops = U.ops
     x = q16(torch.tensor(detrand.uniform("hx16", (B, Cc, H, W), -1, 1, np.float64)))
     w = q16(torch.tensor(detrand.uniform("hw16", (6, 6, Cc, 2), -1, 1, np.float64))).requires_grad_(True)

@@ -155,7 +155,7 @@ template <typename T>
 int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
         return UNETRIR_EINVAL;
-    if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip) for images up to 256 pixels wide
+    if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip; images wider than 256 pixels in column blocks)
         const bool mfma = unetrir_cfg().head_mfma != 0;
         if (mfma && head_mfma_applies(W, C) && (ldx & 7) == 0) return launch_head_fwd_mfma(x, ldx, B, H, W, C, w, bias, y, ldy, s);
     }
@@ -174,7 +174,7 @@ int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy
         return UNETRIR_EINVAL;
     if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip)
         const bool mfma = unetrir_cfg().head_mfma != 0;
-        if (mfma && W <= 256 && C % 64 == 0 && (ldx & 7) == 0) {
+        if (mfma && W <= 4096 && C % 64 == 0 && (ldx & 7) == 0) {
             int nb = 0;
             const int err = launch_head_wgrad_mfma(x, ldx, B, H, W, C, dy, lddy, (float*)ws, HEAD_WGRAD_BLOCKS, &nb, s);
             if (err) return err;
@@ -229,7 +229,7 @@ int unetrir_head6x6_dgrad_bf16(const unetrir_bf16* dy, int lddy, int B, int H, i
     if (!dy || !w || !dx || B <= 0 || H <= 0 || W <= 0 || !head_dgrad_mfma_applies(W, C) || lddy < 2 || (lddy & 1) || lddx < C ||
         (lddx & 7) || ((uintptr_t)dx & 15) || ((uintptr_t)dy & 3))
         return UNETRIR_EINVAL;
-    return launch_head_dgrad_mfma(dy, lddy, B, H, W, w, dx, lddx, (hipStream_t)stream);
+    return launch_head_dgrad_mfma(dy, lddy, B, H, W, w, C, dx, lddx, (hipStream_t)stream);
 }
 
 }  // extern "C"

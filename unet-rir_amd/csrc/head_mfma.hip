@@ -19,16 +19,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define HM_ROWS 32            // output rows per workgroup
 
+// Images wider than 256 pixels (configs[3]: 512) are cut into ncb column blocks of owb <= 250 OUTPUT columns: a workgroup still
+// holds 256 columns of S, those of the input columns g0 .. g0 + 255 with g0 = cb * owb - 2, i.e. its output columns plus the two
+// columns to the left and the three to the right that their horizontal taps reach (S of a column depends on that input column only).
 template <int NCH>
 __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ y, int ldy) {
+                                                             float* __restrict__ y, int ldy, int ncb, int owb) {
     constexpr int C = 32 * NCH;
     __shared__ __attribute__((aligned(16))) float S[2][256][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int nrb = (H + HM_ROWS - 1) / HM_ROWS;
-    const int img = blockIdx.x / nrb, rb = blockIdx.x - img * nrb;
+    const int cb = blockIdx.x % ncb, blk = blockIdx.x / ncb;
+    const int img = blk / nrb, rb = blk - img * nrb;
+    const int g0 = ncb == 1 ? 0 : cb * owb - 2;                      // image column of local column 0
+    const int olo = ncb == 1 ? 0 : cb * owb, ohi = ncb == 1 ? W : min(olo + owb, W);   // output columns of this workgroup
     const int y0 = rb * HM_ROWS;
     const int nrows = (H - y0) < HM_ROWS ? (H - y0) : HM_ROWS;
 
@@ -58,13 +64,13 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
         const bool rok = (unsigned)iy < (unsigned)H;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int q = q0 + 16 * t;
+            const int q = g0 + q0 + 16 * t;                      // image column
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 bf16x8 v;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
-                if (rok && q < W) v = *reinterpret_cast<const bf16x8*>(xb + ((size_t)iy * W + q) * ldx + ch * 32);
+                if (rok && (unsigned)q < (unsigned)W) v = *reinterpret_cast<const bf16x8*>(xb + ((size_t)iy * W + q) * ldx + ch * 32);
                 f[t][ch] = v;
             }
         }
@@ -102,13 +108,13 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
                 acc[(U + 1) % 6][t] = f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
             }                                                                                                    \
             __syncthreads();                                                                                     \
-            if (tid < W) {                                                                                       \
+            if (tid < 256 && g0 + tid >= olo && g0 + tid < ohi) {                                                \
                 float o0 = b0, o1 = b1;                                                                          \
                 _Pragma("unroll") for (int kw = 0; kw < 6; ++kw) {                                               \
                     const int q = tid + kw - 2;                                                                  \
                     if ((unsigned)q < 256u) { o0 += Sb[q][kw]; o1 += Sb[q][6 + kw]; }                            \
                 }                                                                                                \
-                const size_t p = ((size_t)img * H + y0 + orow) * W + tid;                                        \
+                const size_t p = ((size_t)img * H + y0 + orow) * W + g0 + tid;                                   \
                 if (ldy >= 4) *reinterpret_cast<float4*>(y + p * ldy) = make_float4(o0, o1, 0.f, 0.f);           \
                 else { y[p * ldy] = o0; y[p * ldy + 1] = o1; }                                                   \
             }                                                                                                    \
@@ -125,15 +131,17 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
 #undef HM_STEP
 }
 
-bool head_mfma_applies(int W, int C) { return W <= 256 && (C == 32 || C == 64 || C == 128); }
+bool head_mfma_applies(int W, int C) { return W <= 4096 && (C == 32 || C == 64 || C == 128); }
 
 int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy,
                          hipStream_t s) {
-    const unsigned grid = (unsigned)(B * ((H + HM_ROWS - 1) / HM_ROWS));
+    const int ncb = W <= 256 ? 1 : (W + 249) / 250;                  // column blocks of at most 250 output columns (+ 2 + 3 halo = 255 <= 256)
+    const int owb = (W + ncb - 1) / ncb;
+    const unsigned grid = (unsigned)(B * ((H + HM_ROWS - 1) / HM_ROWS) * ncb);
     const __bf16* xp = (const __bf16*)x;
-    if (C == 32) hipLaunchKernelGGL((head_fwd_mfma_kernel<1>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy);
-    else if (C == 64) hipLaunchKernelGGL((head_fwd_mfma_kernel<2>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy);
-    else hipLaunchKernelGGL((head_fwd_mfma_kernel<4>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy);
+    if (C == 32) hipLaunchKernelGGL((head_fwd_mfma_kernel<1>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb);
+    else if (C == 64) hipLaunchKernelGGL((head_fwd_mfma_kernel<2>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb);
+    else hipLaunchKernelGGL((head_fwd_mfma_kernel<4>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb);
     return (int)hipGetLastError();
 }
 
@@ -174,8 +182,13 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 
     const int g8 = tid & 7, qsub = tid >> 3;          // x staging: 16-byte granule g8 of pixel qsub + 32*j
     uint4 rx[8];
-    for (int blk = blockIdx.x; blk < B * nrb; blk += gridDim.x) {
-        const int img = blk / nrb, rb = blk - img * nrb;
+    // images wider than 256 pixels: column blocks of 256 x columns (a partition - the sum over pixels needs no halo of x); the shifted
+    // copies D' of a block reach three dy columns to its left and two to its right, which five threads load beside the block's own
+    const int ncb = (W + 255) / 256;
+    for (int blk = blockIdx.x; blk < B * nrb * ncb; blk += gridDim.x) {
+        const int cb = blk % ncb, ib = blk / ncb;
+        const int img = ib / nrb, rb = ib - img * nrb;
+        const int g0 = cb * 256;                          // image column of local column 0
         const int y0 = rb * HW_ROWS;
         const int nrows = (H - y0) < HW_ROWS ? (H - y0) : HW_ROWS;
         const __bf16* xi = x + (size_t)img * H * W * ldx + c0 + g8 * 8;
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
             const bool rok = (unsigned)iy < (unsigned)H;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int q = qsub + 32 * j;
+                const int q = g0 + qsub + 32 * j;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (rok && q < W) v = *reinterpret_cast<const uint4*>(xi + ((size_t)iy * W + q) * ldx);
                 rx[j] = v;
@@ -193,11 +206,17 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         auto load_dy = [&](int r) {                   // dy row y0 + r (zeros outside the block / image columns)
             bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
-            if (r < nrows && tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)(y0 + r) * W + tid) * lddy);
+            if (r < nrows && g0 + tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)(y0 + r) * W + g0 + tid) * lddy);
+            return d;
+        };
+        const int hcol = g0 + (tid < 3 ? tid - 3 : 253 + tid);        // threads 0..4: the halo columns g0-3..g0-1, g0+256, g0+257
+        auto load_dy_halo = [&](int r) {
+            bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
+            if (tid < 5 && r < nrows && (unsigned)hcol < (unsigned)W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)(y0 + r) * W + hcol) * lddy);
             return d;
         };
         load_x(y0 - 2);
-        bf16x2 dnext = load_dy(0);
+        bf16x2 dnext = load_dy(0), dhalo = load_dy_halo(0);
         const int nsteps = nrows + 5;
         for (int i = 0; i < nsteps; ++i) {
             const int iy = y0 - 2 + i;
@@ -206,7 +225,10 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 #pragma unroll
             for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(Xb + (qsub + 32 * j) * HW_XL + g8 * 8) = rx[j];
             const bool newdy = i < nrows;             // dy row y0 + i enters the ring (vertical tap kh = 0 of this x row)
-            if (newdy) { dyrow[0][tid + 3] = dnext[0]; dyrow[1][tid + 3] = dnext[1]; }
+            if (newdy) {
+                dyrow[0][tid + 3] = dnext[0]; dyrow[1][tid + 3] = dnext[1];
+                if (tid < 5) { const int hi_ = tid < 3 ? tid : 256 + tid; dyrow[0][hi_] = dhalo[0]; dyrow[1][hi_] = dhalo[1]; }
+            }
             __syncthreads();
             if (newdy) {
                 __bf16* Db = Dp[(y0 + i) % 6];
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 #pragma unroll
                     for (int kw = 0; kw < 6; ++kw) Db[(n * 6 + kw) * HW_DL + tid] = dyrow[n][tid - kw + 2 + 3];
             }
-            if (i + 1 < nsteps) { load_x(iy + 1); dnext = load_dy(i + 1); }
+            if (i + 1 < nsteps) { load_x(iy + 1); dnext = load_dy(i + 1); dhalo = load_dy_halo(i + 1); }
             __syncthreads();
             if ((unsigned)iy < (unsigned)H) {
                 // ring slot of each vertical tap's dy row (wave-uniform), -1 where that row is outside the block
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
                            int* nblk_out, hipStream_t s) {
-    int nblk = B * ((H + HW_ROWS - 1) / HW_ROWS);
+    int nblk = B * ((H + HW_ROWS - 1) / HW_ROWS) * ((W + 255) / 256);
     if (nblk > max_blocks) nblk = max_blocks;
     *nblk_out = nblk;
     hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nblk, C / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
@@ -291,15 +313,22 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
 // ------------------------------------------------------------------------------------------------------------------
 #define HD_ROWS 16            // output rows per workgroup
 
+// C = 64 channels per workgroup: blockIdx.y picks the 64-channel block of a wider layer (configs[3]: 128); images wider than 256
+// pixels run in column blocks of 256 output columns, whose dy rows carry three more columns to the left and two to the right
+// (the reach of the horizontal taps), loaded by five threads beside the block's own.
 __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __restrict__ dy, int lddy, int B, int H, int W,
-                                                              const float* __restrict__ w, __bf16* __restrict__ dx, int lddx) {
-    constexpr int C = 64;
+                                                              const float* __restrict__ w, int C, __bf16* __restrict__ dx, int lddx,
+                                                              int ncb) {
     __shared__ __attribute__((aligned(16))) __bf16 Dq[6][256 * 16];        // 49152 B
     __shared__ __attribute__((aligned(16))) __bf16 dyrow[2][272];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
     const int nrb = (H + HD_ROWS - 1) / HD_ROWS;
-    const int img = blockIdx.x / nrb, rb = blockIdx.x - img * nrb;
+    const int cb = blockIdx.x % ncb, ib = blockIdx.x / ncb;
+    const int img = ib / nrb, rb = ib - img * nrb;
+    const int g0 = cb * 256;                              // image column of local column 0
+    const int c0 = blockIdx.y * 64;                       // first channel of this workgroup
+    const int hcol = g0 + (tid < 3 ? tid - 3 : 253 + tid);        // threads 0..4: halo columns g0-3..g0-1, g0+256, g0+257
     const int y0 = rb * HD_ROWS;
     const int nrows = (H - y0) < HD_ROWS ? (H - y0) : HD_ROWS;
     const __bf16* di = dy + (size_t)img * H * W * lddy;
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
                 float f = 0.f;
                 if (idx < 12) {
                     const int n = idx / 6, kw = idx - n * 6;
-                    f = w[(size_t)(n * 36 + kh * 6 + kw) * C + 32 * (ct >> 1) + 8 * (l15 >> 2) + 4 * (ct & 1) + (l15 & 3)];
+                    f = w[(size_t)(n * 36 + kh * 6 + kw) * C + c0 + 32 * (ct >> 1) + 8 * (l15 >> 2) + 4 * (ct & 1) + (l15 & 3)];
                 }
                 v[j] = (__bf16)f;
             }
@@ -332,10 +361,12 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
     // previous expansion's reads of the staging row are not already behind a barrier (back-to-back calls in the prologue)
     auto push_row = [&](int r, bool guard) {
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        bf16x2 d; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f;
-        if ((unsigned)r < (unsigned)H && tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)r * W + tid) * lddy);
+        bf16x2 d, dh; d[0] = (__bf16)0.f; d[1] = (__bf16)0.f; dh = d;
+        if ((unsigned)r < (unsigned)H && g0 + tid < W) d = *reinterpret_cast<const bf16x2*>(di + ((size_t)r * W + g0 + tid) * lddy);
+        if (tid < 5 && (unsigned)r < (unsigned)H && (unsigned)hcol < (unsigned)W) dh = *reinterpret_cast<const bf16x2*>(di + ((size_t)r * W + hcol) * lddy);
         if (guard) __syncthreads();
         dyrow[0][tid + 3] = d[0]; dyrow[1][tid + 3] = d[1];
+        if (tid < 5) { const int hi_ = tid < 3 ? tid : 256 + tid; dyrow[0][hi_] = dh[0]; dyrow[1][hi_] = dh[1]; }
         __syncthreads();
         bf16x8 lo, hi;
 #pragma unroll
@@ -379,22 +410,24 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
         __bf16* orow = dx + ((size_t)img * H + yo) * W * lddx;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int q = wave * 64 + 16 * t + l15;
+            const int q = g0 + wave * 64 + 16 * t + l15;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[t][2 * m + (e >> 2)][e & 3];
-                if (q < W) *reinterpret_cast<bf16x8*>(orow + (size_t)q * lddx + 32 * m + 8 * lq) = o;
+                if (q < W) *reinterpret_cast<bf16x8*>(orow + (size_t)q * lddx + c0 + 32 * m + 8 * lq) = o;
             }
         }
     }
 }
 
-bool head_dgrad_mfma_applies(int W, int C) { return W <= 256 && C == 64; }
+bool head_dgrad_mfma_applies(int W, int C) { return W <= 4096 && C >= 64 && C <= 512 && C % 64 == 0; }
 
-int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s) {
-    const unsigned grid = (unsigned)(B * ((H + HD_ROWS - 1) / HD_ROWS));
-    hipLaunchKernelGGL(head_dgrad_mfma_kernel, dim3(grid), dim3(256), 0, s, (const __bf16*)dy, lddy, B, H, W, w, (__bf16*)dx, lddx);
+int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, int C, void* dx, int lddx, hipStream_t s) {
+    const int ncb = (W + 255) / 256;
+    const unsigned grid = (unsigned)(B * ((H + HD_ROWS - 1) / HD_ROWS) * ncb);
+    hipLaunchKernelGGL(head_dgrad_mfma_kernel, dim3(grid, C / 64), dim3(256), 0, s, (const __bf16*)dy, lddy, B, H, W, w, C, (__bf16*)dx, lddx,
+                       ncb);
     return (int)hipGetLastError();
 }

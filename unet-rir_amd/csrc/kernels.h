@@ -128,7 +128,7 @@ int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, con
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
                            int* nblk_out, hipStream_t s);
 bool head_dgrad_mfma_applies(int W, int C);
-int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, void* dx, int lddx, hipStream_t s);
+int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, int C, void* dx, int lddx, hipStream_t s);
 bool upconv3x3g_applies(const Conv3Args& a);
 bool upconv3x3q_applies(const Conv3Args& a);        // upconv3x3g's layers with >= 512 tiles: persistent form
 int launch_upconv3x3q_bf16(const Conv3Args& a, hipStream_t s);
