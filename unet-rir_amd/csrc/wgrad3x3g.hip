@@ -337,7 +337,10 @@ static void plan_g(int B, int OH, int OW, int N, int C, int* nsplit, int* per_sp
 int launch_wgrad3x3g_bf16(Wgrad3ArgsH a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
     const bool on = unetrir_cfg().wgrad3x3g != 0;
     const size_t x_bytes = (((size_t)a.IH * a.IW - 1) * a.ldx + a.C) * 2, d_bytes = (((size_t)a.OH * a.OW - 1) * a.lddy + a.N) * 2;
-    if (!on || a.OH % 8 != 0 || x_bytes >= 0x70000000u || d_bytes >= 0x70000000u || (a.C & 7) || (a.N & 7)) return WGRAD3X3R_NOT_TAKEN;
+    // heights that are not a multiple of the 8-row patch: the rows past the image are zero-filled DMAs (as the columns past OW);
+    // taken while at least 60 % of the patch rows are real (the reference's 144 x 160 geometry: 36 and 18 rows)
+    const int rows8 = (a.OH + 7) / 8 * 8;
+    if (!on || a.OH * 10 < rows8 * 6 || x_bytes >= 0x70000000u || d_bytes >= 0x70000000u || (a.C & 7) || (a.N & 7)) return WGRAD3X3R_NOT_TAKEN;
     int ns, per;
     plan_g(a.B, a.OH, a.OW, a.N, a.C, &ns, &per, &a.npy, &a.npx);
     const int nh = ns >= 2 ? 2 : 1;                       // two split-K quartets per workgroup share one partial slab
