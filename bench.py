@@ -162,11 +162,12 @@ class Runner:
             dt = float(t[0])
         return dt, fam
 
-    def engine_run(self, dtype, steps, warmup, overlap, prof=True, f0=None, size=None, depth=None, batch=None):
-        """Trainer.step over a UNetEngine.  Returns a result dict."""
+    def engine_run(self, dtype, steps, warmup, overlap, prof=True, f0=None, size=None, depth=None, batch=None, hw=None):
+        """Trainer.step over a UNetEngine.  Returns a result dict.  hw: (H, W) of a non-square input."""
         U, a = self.U, self.args
         f0, size, depth, batch = f0 or a.f0, size or a.size, depth or a.depth, batch or a.batch
-        eng = U.UNetEngine(size, size, batch, F0=f0, k=3, depth=depth, device=self.device, n_replicas=self.world, dtype=dtype,
+        H_, W_ = hw if hw is not None else (size, size)
+        eng = U.UNetEngine(H_, W_, batch, F0=f0, k=3, depth=depth, device=self.device, n_replicas=self.world, dtype=dtype,
                            overlap_wgrad=overlap)
         gen = torch.Generator()
         gen.manual_seed(0)                                   # identical initial variables on every replica
@@ -175,7 +176,7 @@ class Runner:
         tr = U.Trainer(eng, lr=5e-7, alpha=0.9, world_size=self.world, bucket_bytes=a.bucket_mb << 20, dropout=True,
                        force_dp=a.force_dp)
         tr.broadcast_parameters(0)
-        spec_in, emb, spec_out = synthetic_batch(batch, size, size, self.device, 1234 + self.rank)
+        spec_in, emb, spec_out = synthetic_batch(batch, H_, W_, self.device, 1234 + self.rank)
         # overlapped schedule: only the forward brackets are clean kernel durations, so only those are taken (level 2) - every
         # bracket is two event records in the stream (~8 us of dispatch gap each)
         level = 0 if (not prof or a.no_prof or self.rank != 0) else (2 if overlap and not a.prof_all else 1)
@@ -372,6 +373,12 @@ def main():
                 "workload": "BASELINE.json configs[3]'s model on ONE GPU: UNet 5 down/5 up, number_filters_0=128, kernels=3, batch 16 of "
                             "[2,512,512], full train step, bf16 storage", "value": c4["value"], "unit": "spectrograms/s",
                 "ms_per_step": c4["ms_per_step"], "steps": c4["steps"], "warmup": c4["warmup"], "params": c4["params"], "dtype": "bf16"}
+            rg = run.engine_run("bf16", 10, 3, overlap, prof=False, f0=32, hw=(144, 160), depth=4, batch=32)
+            configs["reference_geometry"] = {
+                "workload": "the reference's own training geometry (main_training.py:154-161: target_size (144,160,2), number_filters_0=32, "
+                            "kernels=3; 9 x 10 bottleneck), batch 32, full train step, bf16 storage - not a BASELINE.json config",
+                "value": rg["value"], "unit": "spectrograms/s", "ms_per_step": rg["ms_per_step"], "steps": rg["steps"],
+                "warmup": rg["warmup"], "params": rg["params"], "dtype": "bf16"}
             configs["cfg5_resae"] = run.resae_run(5, 2, "bf16")
             configs["cfg5_resae_fp32"] = run.resae_run(5, 2, "f32")
     if rank != 0:
