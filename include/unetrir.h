@@ -334,7 +334,7 @@ int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, 
 int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream);
 /* head data gradient on the matrix cores: dx[p][c] = sum_{n<2,kh,kw} dy[p - off][n] * w[n][kh][kw][c] (the adjoint of
  * unetrir_head6x6_fwd_bf16; w is the fp32 [>=2][6][6][C] kernel, rounded to bf16 on load).  Only channels 0,1 of dy are
- * read.  Supported for C a multiple of 64 up to 512 (unetrir_head6x6_dgrad_supported; 64 channels per workgroup, images wider
+ * read.  Supported for C a multiple of 32 up to 512 (unetrir_head6x6_dgrad_supported; 64 channels per workgroup, images wider
  * than 256 pixels in column blocks); otherwise UNETRIR_EINVAL and the caller uses unetrir_conv2d_dgrad_bf16 on the padded kernel. */
 int unetrir_head6x6_dgrad_supported(int W, int C);
 int unetrir_head6x6_dgrad_bf16(const unetrir_bf16* dy, int lddy, int B, int H, int W, const float* w, int C,

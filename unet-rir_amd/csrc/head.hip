@@ -174,7 +174,7 @@ int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy
         return UNETRIR_EINVAL;
     if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip)
         const bool mfma = unetrir_cfg().head_mfma != 0;
-        if (mfma && W <= 4096 && C % 64 == 0 && (ldx & 7) == 0) {
+        if (mfma && W <= 4096 && C % 32 == 0 && (ldx & 7) == 0) {
             int nb = 0;
             const int err = launch_head_wgrad_mfma(x, ldx, B, H, W, C, dy, lddy, (float*)ws, HEAD_WGRAD_BLOCKS, &nb, s);
             if (err) return err;

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
             for (int j = 0; j < 8; ++j) {
                 const int q = g0 + qsub + 32 * j;
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (rok && q < W) v = *reinterpret_cast<const uint4*>(xi + ((size_t)iy * W + q) * ldx);
+                if (rok && q < W && c0 + g8 * 8 < C) v = *reinterpret_cast<const uint4*>(xi + ((size_t)iy * W + q) * ldx);   // C = 32: half a block
                 rx[j] = v;
             }
         };
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = 4 * lq + j;
-            if (idx < 12) {
+            if (idx < 12 && c < C) {
                 const int n = idx / 6, kw = idx - n * 6;
                 out[(size_t)(n * 36 + kh * 6 + kw) * C + c] = acc[kh][j];
             }
@@ -295,7 +295,7 @@ int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, c
     int nblk = B * ((H + HW_ROWS - 1) / HW_ROWS) * ((W + 255) / 256);
     if (nblk > max_blocks) nblk = max_blocks;
     *nblk_out = nblk;
-    hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nblk, C / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
+    hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nblk, (C + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
                        (const __bf16*)dy, lddy, part);
     return (int)hipGetLastError();
 }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
             for (int j = 0; j < 8; ++j) {
                 const int idx = 8 * (lq & 1) + j;
                 float f = 0.f;
-                if (idx < 12) {
+                if (idx < 12 && c0 + 32 * (ct >> 1) < C) {            // C = 32: the upper half of the block does not exist
                     const int n = idx / 6, kw = idx - n * 6;
                     f = w[(size_t)(n * 36 + kh * 6 + kw) * C + c0 + 32 * (ct >> 1) + 8 * (l15 >> 2) + 4 * (ct & 1) + (l15 & 3)];
                 }
@@ -416,18 +416,18 @@ __global__ __launch_bounds__(256) void head_dgrad_mfma_kernel(const __bf16* __re
                 bf16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[t][2 * m + (e >> 2)][e & 3];
-                if (q < W) *reinterpret_cast<bf16x8*>(orow + (size_t)q * lddx + c0 + 32 * m + 8 * lq) = o;
+                if (q < W && c0 + 32 * m < C) *reinterpret_cast<bf16x8*>(orow + (size_t)q * lddx + c0 + 32 * m + 8 * lq) = o;
             }
         }
     }
 }
 
-bool head_dgrad_mfma_applies(int W, int C) { return W <= 4096 && C >= 64 && C <= 512 && C % 64 == 0; }
+bool head_dgrad_mfma_applies(int W, int C) { return W <= 4096 && C >= 32 && C <= 512 && C % 32 == 0; }
 
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, int C, void* dx, int lddx, hipStream_t s) {
     const int ncb = (W + 255) / 256;
     const unsigned grid = (unsigned)(B * ((H + HD_ROWS - 1) / HD_ROWS) * ncb);
-    hipLaunchKernelGGL(head_dgrad_mfma_kernel, dim3(grid, C / 64), dim3(256), 0, s, (const __bf16*)dy, lddy, B, H, W, w, C, (__bf16*)dx, lddx,
+    hipLaunchKernelGGL(head_dgrad_mfma_kernel, dim3(grid, (C + 63) / 64), dim3(256), 0, s, (const __bf16*)dy, lddy, B, H, W, w, C, (__bf16*)dx, lddx,
                        ncb);
     return (int)hipGetLastError();
 }
