@@ -4,6 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import unet_rir_amd as U
+if "--lib" in sys.argv:      # another build of the library (A/B of two builds, one process each)
+    U._lib.use_library(os.path.abspath(sys.argv[sys.argv.index("--lib") + 1]))
+    del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 ops = U.ops
 dev = "cuda:0"
 

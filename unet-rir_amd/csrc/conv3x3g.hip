@@ -69,7 +69,7 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
     constexpr int WB = 3 * BN * 64;                        // one kernel tile: [3 vertical taps][BN channels][32 input channels]
     constexpr int W_INSTR = WB / 1024;                     // 24 / 12 wave-instructions
     constexpr int WPW = (W_INSTR + 7) / 8;                 // 3 / 2 per wave
-    static_assert(BN == 128 || (BN == 64 && PAIR && (VAR & 2)), "64-channel tiles exist for the paired 16x16x32 body");
+    static_assert(BN == 128 || (BN == 64 && (VAR & 2)), "64-channel tiles exist for the 16x16x32 body");
     constexpr int PC = PAIR ? 18 : GPC;                    // patch columns
     constexpr int NPX = PAIR ? 36 * 18 : GNPX;             // patch pixels
     constexpr int P_INSTR = (NPX + 15) / 16;               // 41 / 39 wave-instructions
@@ -426,7 +426,8 @@ __global__ __launch_bounds__(512) void conv3x3g_bf16_kernel(const Conv3Args a) {
 // true when the LDS-DMA kernel takes this layer (bf16, C a multiple of 32, more than 64 output channels)
 bool conv3x3g_applies(const Conv3Args& a) {
     const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2, w_bytes = (size_t)a.N * 9 * a.C * 2;
-    return a.C % 32 == 0 && a.N > 64 && !(a.flip & 2) && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
+    // N = 64 with more than 64 input channels (the 128 -> 64 layer behind the first skip concat): 64-channel tiles, launch_conv3x3g_bf16
+    return a.C % 32 == 0 && (a.N > 64 || (a.N == 64 && a.C > 64)) && !(a.flip & 2) && img_bytes < 0x70000000u && w_bytes < 0x70000000u;
 }
 
 // images at most 16 pixels wide: the paired-image tile (full tiles where the 32-column tile would be half empty)
@@ -455,6 +456,11 @@ int launch_conv3x3g_bf16(const Conv3Args& a, hipStream_t s) {
             return (int)hipGetLastError();
         }
         hipLaunchKernelGGL((conv3x3g_bf16_kernel<2, true>), dim3((unsigned)tiles), dim3(512), 0, s, a);
+        return (int)hipGetLastError();
+    }
+    if (a.N <= 64) {                                          // one 64-channel tile per pixel tile
+        const long long t64 = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32);
+        hipLaunchKernelGGL((conv3x3g_bf16_kernel<2, false, 64>), dim3((unsigned)t64), dim3(512), 0, s, a);
         return (int)hipGetLastError();
     }
     const long long tiles = (long long)a.B * ((a.H + GTR - 1) / GTR) * ((a.W + 31) / 32) * ((a.N + GBN - 1) / GBN);

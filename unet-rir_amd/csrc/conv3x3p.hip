@@ -466,7 +466,7 @@ inline long long pixel_tiles(const Conv3Args& a) { return (long long)a.B * ((a.H
 
 bool conv3x3p_applies(const Conv3Args& a) {
     const int ntN = (a.N + PBN - 1) / PBN;
-    return unetrir_cfg().conv3x3p && conv3x3g_applies(a) && !conv3x3g_pair_applies(a) && (a.N & 7) == 0 && a.C >= 64 &&
+    return unetrir_cfg().conv3x3p && conv3x3g_applies(a) && a.N > 64 && !conv3x3g_pair_applies(a) && (a.N & 7) == 0 && a.C >= 64 &&
            (ntN == 1 || ntN == 2 || ntN == 4 || ntN == 8) && pixel_tiles(a) * ntN >= 512;
 }
 
