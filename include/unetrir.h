@@ -20,9 +20,11 @@
  *     distinct streams.  The library holds three pieces of process-global state, documented
  *     where they are declared: the kernel-selection switches (unetrir_config), the profiling
  *     brackets (unetrir_prof_*), and the tile-ticket slots of the persistent convolution
- *     kernels - a static device array of counters, one slot per stream that has launched
- *     such a kernel (at most 128 streams; beyond that the kernels fall back to a fixed tile
- *     assignment), zero between launches; no memory is allocated for it;
+ *     kernels - a static device array of counters PER DEVICE (resolved for the device that is
+ *     current at the launch; up to 16 devices per process), one slot per (device, stream) that
+ *     has launched such a kernel (at most 128 streams per device; beyond that the kernels fall
+ *     back to a fixed tile assignment), zero between launches (unetrir_reset_tile_tickets
+ *     clears them from the host after a failed launch); no memory is allocated for it;
  *   - return 0 on success, a hipError_t value or UNETRIR_EINVAL otherwise.
  */
 #ifndef UNETRIR_H
@@ -82,6 +84,10 @@ typedef struct {
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);
+/* Zero every tile-ticket slot of the CURRENT device from the host (synchronous; call with the device idle): after a launch that
+ * failed or was aborted, or when dyn_tiles is toggled between launches.  A healthy run never needs it - the last workgroup of
+ * every persistent launch clears its own slot. */
+int unetrir_reset_tile_tickets(void);
 
 /* ---- Conv2D(padding='same'): dl_models/u_net.py:269-276 (strided, stride 1|2),
  *      :366 (3x3 block conv), :248 (6x6 head), :262 (1x1 on the information vector).
@@ -195,6 +201,13 @@ size_t unetrir_loss_ws_bytes(long long npix);
 int unetrir_sigmoid_loss_f32(const float* logits, int ldl, const float* target, int B, int H, int W,
                              float alpha, float inv_norm, float* pred, float* dlogits,
                              float* loss_out, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* The same with the two switches of compute_loss (main_training.py:38-39): `phase_ref` (nullable; diff_loss, :214-217) = the
+ * network INPUT, NCHW [B,2,H,W]: the phase target becomes target[:,1] - phase_ref[:,1]; `phase_weight` (nullable; sigmoid_loss,
+ * :221-222 with preprocess.py:116-121) = [W] column weights multiplied into the phase term of the loss and its gradient.
+ * loss_out[2] stays the UNWEIGHTED phase sum (the train_loss_phase metric, main_training.py:278-284). */
+int unetrir_sigmoid_loss_ex_f32(const float* logits, int ldl, const float* target, const float* phase_ref,
+                                const float* phase_weight, int B, int H, int W, float alpha, float inv_norm, float* pred,
+                                float* dlogits, float* loss_out, void* ws, size_t ws_bytes, unetrir_stream_t stream);
 /* sigmoid only (inference / forward without a target) */
 int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, float* pred,
                              unetrir_stream_t stream);
@@ -233,6 +246,23 @@ int unetrir_sumsq_f32(const float* x, long long n, float coef, float* out, int a
 int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long n, float lr_t,
                      float beta1, float beta2, float eps, float grad_scale,
                      unetrir_stream_t stream);
+
+/* ---- step counters in DEVICE memory, so that a whole train step can be captured once into a HIP graph and replayed: the values
+ *      that change from step to step (Adam's bias-corrected rate, the dropout draw number) are then read by the kernels instead
+ *      of being launch arguments.
+ *      state: 3 x uint64 {Adam step count t, dropout draws made so far, first draw of the current step};
+ *      cfg:   5 x float  {lr, beta1, beta2, eps, grad_scale} as the host last set them;
+ *      hyper: 5 x float  written by step_advance: {lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), beta1, beta2, eps, grad_scale}.
+ *      step_advance:      t += 1 (advance_t != 0), hyper from cfg, state[2] = state[1], state[1] += n_draws (one launch at the
+ *                         start of a step; advance_t = 0 for a forward-only pass that draws dropout masks).
+ *      adam_dev:          unetrir_adam_f32 with its five scalars read from `hyper`.
+ *      dropout_mask_dev:  unetrir_dropout_mask_f32 with draw number *step_base + step_offset (step_base = state + 2). */
+int unetrir_step_advance(unsigned long long* state, const float* cfg, float* hyper, int n_draws, int advance_t,
+                         unetrir_stream_t stream);
+int unetrir_adam_dev_f32(float* theta, const float* g, float* m, float* v, long long n, const float* hyper,
+                         unetrir_stream_t stream);
+int unetrir_dropout_mask_dev_f32(float* mask, long long n, float p, unsigned long long seed,
+                                 const unsigned long long* step_base, unsigned long long step_offset, unetrir_stream_t stream);
 
 /* ---- bf16-storage variants (BASELINE.json configs[1] names bf16): activations, their gradients and the weight work
  *      copies are bfloat16 (unetrir_bf16), accumulation is fp32 (v_mfma_f32_32x32x16_bf16), bias / BatchNorm parameters /
@@ -343,6 +373,9 @@ int unetrir_head6x6_dgrad_bf16(const unetrir_bf16* dy, int lddy, int B, int H, i
 int unetrir_sigmoid_loss_bf16(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha,
                               float inv_norm, float* pred, unetrir_bf16* dlogits, float* loss_out, void* ws,
                               size_t ws_bytes, unetrir_stream_t stream);
+int unetrir_sigmoid_loss_ex_bf16(const float* logits, int ldl, const float* target, const float* phase_ref,
+                                 const float* phase_weight, int B, int H, int W, float alpha, float inv_norm, float* pred,
+                                 unetrir_bf16* dlogits, float* loss_out, void* ws, size_t ws_bytes, unetrir_stream_t stream);
 int unetrir_sigmoid_bwd_bf16(const float* pred, const float* dpred, int B, int H, int W, unetrir_bf16* dlogits,
                              unetrir_stream_t stream);
 /* glue between the bf16 trunk and the fp32 information-vector branch: y = a + b (Add(), dl_models/u_net.py:229);

@@ -330,15 +330,27 @@ def forward(P: Dict[str, torch.Tensor], spec, emb, cfg: Config, training=True,
     return torch.sigmoid(x)
 
 
-def data_loss(y_true, y_pred, alpha=0.9, global_batch=None):
-    """compute_loss without the regulariser (main_training.py:203-231), NCHW."""
+def sigmoid_weight(beta, W, dtype=torch.float64):
+    """preprocess.sigmoid (preprocess.py:116-121): the column weights of the `sigmoid_loss` switch - z = 1/(1+exp(-(x+5) beta)) on
+    x = linspace(-10, 10, W), flipped (every row of the [H, W] mask is this vector)."""
+    x = torch.linspace(-10.0, 10.0, W, dtype=torch.float64)
+    return torch.flip(1.0 / (1.0 + torch.exp(-(x + 5.0) * beta)), dims=(0,)).to(dtype)
+
+
+def data_loss(y_true, y_pred, alpha=0.9, global_batch=None, x_in=None, phase_weight=None):
+    """compute_loss without the regulariser (main_training.py:203-231), NCHW.
+    x_in (the `diff_loss` switch, :214-217): the network input; the phase target becomes phase_true - phase_x.
+    phase_weight (the `sigmoid_loss` switch, :221-222): [W] column weights multiplied into the phase term (sigmoid_weight)."""
     B, _, H, W = y_true.shape
     gb = B if global_batch is None else global_batch
     e_amp = (y_true[:, 0] - y_pred[:, 0]) ** 2
-    yt = y_true[:, 1] * 2 * math.pi - math.pi
+    pt = y_true[:, 1] if x_in is None else y_true[:, 1] - x_in[:, 1]
+    yt = pt * 2 * math.pi - math.pi
     yp = y_pred[:, 1] * 2 * math.pi - math.pi
     ph = torch.remainder((yt - yp) + math.pi, 2 * math.pi) - math.pi   # phase_loss :184-190
     e_ph = 1.0 - torch.cos(ph)
+    if phase_weight is not None:
+        e_ph = e_ph * phase_weight.to(e_ph.dtype).view(1, 1, W)
     per = alpha * e_amp + (1.0 - alpha) * e_ph
     return per.sum() / (H * W * 2) / gb
 

@@ -237,16 +237,18 @@ class CpuOps:
         (gw,) = torch.autograd.grad(out, w0, dy.base[..., :2].to(D).permute(0, 3, 1, 2))
         dw.reshape(-1, 6, 6, x.C)[:2] = gw.permute(3, 0, 1, 2).to(dw.dtype)
 
-    def sigmoid_loss(self, logits, target, alpha, inv_norm, pred, dlogits, loss_out, ws):
-        self.rt.touch([logits, target], [pred, dlogits, loss_out, ws], "sigmoid_loss")
+    def sigmoid_loss(self, logits, target, alpha, inv_norm, pred, dlogits, loss_out, ws, phase_ref=None, phase_weight=None):
+        self.rt.touch([logits, target, phase_ref, phase_weight], [pred, dlogits, loss_out, ws], "sigmoid_loss")
         z = logits.base[..., :2].to(D).permute(0, 3, 1, 2).clone().requires_grad_(True)
         p = torch.sigmoid(z)
         t = target.to(D)
         e_amp = (t[:, 0] - p[:, 0]) ** 2
-        d = (t[:, 1] - p[:, 1]) * 2 * math.pi
+        t1 = t[:, 1] if phase_ref is None else t[:, 1] - phase_ref.to(D)[:, 1]
+        d = (t1 - p[:, 1]) * 2 * math.pi
         ph = torch.remainder(d + math.pi, 2 * math.pi) - math.pi
         e_ph = 1.0 - torch.cos(ph)
-        loss = (alpha * e_amp + (1 - alpha) * e_ph).sum() * inv_norm
+        e_w = e_ph if phase_weight is None else e_ph * phase_weight.to(D).view(1, 1, -1)
+        loss = (alpha * e_amp + (1 - alpha) * e_w).sum() * inv_norm
         (gz,) = torch.autograd.grad(loss, z)
         pred.copy_(p.detach().float())
         dlogits.base.zero_()

@@ -59,6 +59,8 @@ def _windows(H, W, step=1):
     """(r0, r1, c0, c1) output windows; even offsets so that they are also valid origins of a stride-2 grid."""
     hh, ww = min(H, 24), min(W, 40)
     out = [(0, hh, 0, ww), (H - hh, H, W - ww, W)]
+    if H <= 64 and W <= 64:          # the small levels: one more window across the 16-row / 32-column seams of the interior
+        out.append((H // 2 - 8, H // 2 + 8, max(W // 2 - 16, 0), min(W // 2 + 16, W)))
     if H >= 64 and W >= 96:
         out.append((8, 40, 24, 72))                                   # straddles 8- / 16-row and 32-column tile seams
         out.append((H // 2 - 12, H // 2 + 12, W // 2 - 20, W // 2 + 20))
@@ -118,9 +120,13 @@ def _convT_windows(y_gpu, x_gpu, k_hwoi, bias, what):
 # (Cin, Cout, input size, pixel stride of the input buffer): the stride-1 3x3 layers of configs[1] by serving kernel
 S1_LAYERS = [
     (64, 64, 256, 64),        # enc1.cb1 / dec1.cb1b and their data gradients: conv3x3s
-    (128, 64, 256, 128),      # dec1.cb1a forward on the concat buffer: conv3x3h;  data gradient 64 -> 128: conv3x3g
-    (128, 128, 128, 128),     # enc2.cb1 / dec2.cb1b: conv3x3g
-    (256, 128, 128, 256),     # dec2.cb1a on the concat buffer: conv3x3g
+    (128, 64, 256, 128),      # dec1.cb1a forward on the concat buffer: conv3x3g with 64-channel tiles;  data gradient 64 -> 128: conv3x3p
+    (128, 128, 128, 128),     # enc2.cb1 / dec2.cb1b: conv3x3p
+    (256, 128, 128, 256),     # dec2.cb1a on the concat buffer: conv3x3p
+    (256, 256, 64, 256),      # enc3.cb1 / dec3.cb1b: conv3x3p, two channel tiles
+    (512, 256, 64, 512),      # dec3.cb1a on the concat buffer (data gradient 256 -> 512: four channel tiles)
+    (512, 512, 32, 512),      # enc4.cb1 / dec4.cb1b: conv3x3g, four channel tiles
+    (1024, 512, 32, 1024),    # dec4.cb1a on the concat buffer (data gradient 512 -> 1024: eight channel tiles)
 ]
 
 

@@ -654,6 +654,57 @@ def test_persistent_conv3x3p_equals_conv3x3g_bit_for_bit(U, case):
     assert torch.equal(y3.base, res[1][6]) and torch.equal(cs3, cs4)
 
 
+@pytest.mark.parametrize("case", [(3, 72, 80, 128, 64), (2, 40, 50, 256, 64), (4, 64, 64, 96, 64)])
+def test_conv3x3g_64_channel_tiles_serve_the_n64_layers(U, case):
+    """N = 64 output channels with C > 64 (dec1.cb1a: 128 -> 64 behind the first skip concat, dl_models/u_net.py:309) run on
+    conv3x3g's 64-channel-tile instantiation: forward (bias, addend, fused column statistics over its eight row groups) and the
+    flip = 1 data gradient form, sizes that are not multiples of the 16 x 32 tile (the reference geometry's 72 x 80 among them),
+    against conv3x3h for the same layer (set_config(conv3x3g=0)) - different K order, so to bf16 rounding - and the routing itself."""
+    ops = U.ops
+    B, H, W, Ci, Co = case
+    gen = torch.Generator(device=DEV); gen.manual_seed(H * 100 + Ci)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    g = ops.geom(B, H, W, Ci, Co, 3, 1)            # forward: C = Ci > 64, N = 64
+    gd = ops.geom(B, H, W, Co, Ci, 3, 1)           # a layer whose DATA GRADIENT has C = Ci > 64, N = 64
+    x, add = ops.Act(rnd(B, H, W, Ci + 8), 0, Ci), ops.Act(rnd(B, H, W, Co))
+    w, wt = (rnd(Co, 9, Ci).float() * 0.1).to(torch.bfloat16), (rnd(Co, 9, Ci).float() * 0.1).to(torch.bfloat16)
+    bias = (torch.rand(Co, device=DEV, generator=gen) - 0.5)
+    old = ops.get_config()
+    res = {}
+    try:
+        for on in (1, 0):
+            ops.set_config(conv3x3g=on)
+            assert ops.conv3x3_kernel(g, 0, x) == ("conv3x3g" if on else "conv3x3h")
+            assert ops.conv3x3_kernel(gd, 1, x) == ("conv3x3g" if on else "conv3x3h")
+            rows = ops.conv2d_colstat_rows(g, 0, x)
+            y = ops.Act(torch.full((B, H, W, Co + 8), 3.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+            cs = torch.full((max(rows, 1), Co, 2), 7.0, device=DEV)
+            if rows:
+                ops.conv2d_fwd_colstat(g, x, w, bias, y, cs, addend=add)
+            else:
+                ops.conv2d_fwd(g, x, w, bias, y, addend=add)
+            dx = ops.Act(torch.full((B, H, W, Co), 5.0, dtype=torch.bfloat16, device=DEV))
+            ops.conv2d_dgrad(gd, x, wt, dx)
+            torch.cuda.synchronize()
+            res[on] = (rows, y.base.clone(), cs.double().sum(0) if rows else None, dx.base.clone())
+    finally:
+        ops.set_config(**old)
+    assert res[1][0] > 0
+    assert float(res[1][1][..., Co:].float().min()) == 3.0 and float(res[1][1][..., Co:].float().max()) == 3.0
+    for a, b, what in ((res[1][1][..., :Co], res[0][1][..., :Co], "forward"), (res[1][3], res[0][3], "data gradient")):
+        a, b = a.float(), b.float()
+        assert float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max()), what
+    yd = res[1][1][..., :Co].double()
+    close(res[1][2][:, 0], yd.sum(dim=(0, 1, 2)), 2e-6, "colstat sum (64-channel tiles)")
+    close(res[1][2][:, 1], (yd * yd).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares (64-channel tiles)")
+    # and against the oracle on the first image
+    w_hwio = w.double().cpu().view(Co, 3, 3, Ci).permute(1, 2, 3, 0)
+    want = R.conv2d_same(x.base[:1, ..., :Ci].double().cpu().permute(0, 3, 1, 2), w_hwio, bias.double().cpu(), 1) + \
+        add.base[:1].double().cpu().permute(0, 3, 1, 2)
+    got = res[1][1][:1, ..., :Co].double().cpu().permute(0, 3, 1, 2)
+    assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("case", [(20, 40, 72, 128, 256), (32, 64, 32, 96, 256), (8, 128, 128, 128, 64)])
 def test_persistent_upconv3x3q_equals_upconv3x3g_bit_for_bit(U, case):
     """upconv3x3q (persistent) against upconv3x3g (one workgroup per tile) on layers with >= 512 tiles - Conv2DTranspose forward

@@ -87,6 +87,17 @@ def test_forward_backward_vs_oracle(U, H, W, F0, B, bn, do):
         assert float((a - e).abs().max()) <= 2e-4 * (float(e.abs().max()) + 1e-6), name
 
 
+def test_constructor_defaults_kernels_6_filters_32(U):
+    """UNet(...) with the reference's constructor DEFAULTS (dl_models/u_net.py:40-45: number_filters_0=32, kernels=6): 6x6 strided
+    convolutions (TF 'same' pads (2,2) at stride 2 on even sizes, (2,3) at stride 1), 6x6 stride-2 transposed convolutions
+    (crop 2 / 2) and the 6x6 decoder convolutions behind the skip concat - forward, loss and every gradient against the oracle."""
+    cfg, Pn, eng, tr, ref, _ = run_case(U, 32, 32, 32, 2, k=6)
+    assert eng.k == 6 and eng.F0 == 32 and tuple(eng.specs["enc2.down.kernel"].keras_shape) == (6, 6, 32, 64)
+    check_against_oracle(eng, ref)
+    m = U.UNet((32, 32, 2), (2, 16), batch_size=2, device=DEV)             # every constructor argument at its default
+    assert m.engine.k == 6 and m.engine.F0 == 32 and m.engine.n_params() == eng.n_params()
+
+
 def test_reference_geometry_144x160(U):
     """The reference's own spatial size (main_training.py:27): 144x160 -> 9x10 bottleneck (odd size after the last stride)."""
     # 4.6e5 ReLU inputs of O(1): with an arbitrary input the nearest one to zero is ~1e-7 away, inside fp32 round-off of the

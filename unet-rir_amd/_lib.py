@@ -162,6 +162,14 @@ _SIGS = {
     "unetrir_bn_inference_affine_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_int, c_f32p, c_stream]),
     "unetrir_dropout_mask_f32": (C.c_int, [c_f32p, C.c_longlong, C.c_float, C.c_ulonglong, C.c_ulonglong, c_stream]),
     "unetrir_index_to_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, c_stream]),
+    "unetrir_reset_tile_tickets": (C.c_int, []),
+    "unetrir_sigmoid_loss_ex_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                              c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_sigmoid_loss_ex_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                               c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_step_advance": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, c_stream]),
+    "unetrir_adam_dev_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_longlong, c_f32p, c_stream]),
+    "unetrir_dropout_mask_dev_f32": (C.c_int, [c_f32p, C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p, C.c_ulonglong, c_stream]),
     "unetrir_prof_enable": (C.c_int, [C.c_int]),
     "unetrir_prof_collect": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

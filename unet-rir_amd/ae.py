@@ -12,6 +12,7 @@ from .graph import GraphEngine, Node, RELU
 
 class AutoencoderEngine(GraphEngine):
     """One replica of Autoencoder for a fixed per-replica batch size (constructor mirrors dl_models/autoencoder.py:41-46)."""
+    n_dropout_draws = 2          # two Dropout layers: two masks per step
 
     def __init__(self, H, W, B, conv_filters=(64, 128, 256, 512), conv_kernels=(3, 3, 3, 3), conv_strides=(2, 2, 2, 2),
                  latent_space_dim=64, n_neurons=2048, inf_vector_shape=(2, 16), device="cuda:0", n_replicas=1, runtime=None,
@@ -87,6 +88,7 @@ class AutoencoderEngine(GraphEngine):
             raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor")
         self.set_indices(emb)
         self.masks["inf"], self.masks["dec"] = mask_inf, mask_dec
+        self._last_spec = spec
         ops.nchw_to_nhwc_pad(spec, self.x4.a)
         self.run_forward()
         return self.loss_or_sigmoid(self.logits, target, global_batch, alpha)
@@ -98,6 +100,7 @@ class AutoencoderEngine(GraphEngine):
             raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor")
         self.set_indices(emb)
         self.masks["inf"] = dropout_mask[0] if dropout_mask is not None else None
+        self._last_spec = spec
         ops.nchw_to_nhwc_pad(spec, self.x4.a)
         self.run_forward(0, self._n_enc_ops)
         return self._latent.a.base.view(B, self.latent).clone()

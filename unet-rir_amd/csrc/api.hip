@@ -70,22 +70,39 @@ extern "C" int unetrir_abl_hog(int n, long long cycles, int lds, void* sink, voi
 
 // ---- tile-ticket slots of the persistent kernels (kernels.h): a static device array, one slot per stream in use
 __device__ unsigned g_sched_slots[128][80];
+// A __device__ symbol has one instance PER DEVICE: the table below is keyed by the device that is current at the launch (the
+// reference's own process shape is one process driving several GPUs, main_training.py:56), and a slot by (device, stream).
+// More than 16 devices or 128 streams in use on one device: nullptr, i.e. the kernels keep their fixed tile assignment.
 unsigned* sched_slot(hipStream_t s) {
+    constexpr int MAX_DEV = 16;
+    struct PerDevice { unsigned* base = nullptr; hipStream_t owner[128]; int used = 0; };
     static std::mutex mu;
-    static hipStream_t owner[128];
-    static int used = 0;
-    static unsigned* base = nullptr;
+    static PerDevice tab[MAX_DEV];
     if (!unetrir_cfg().dyn_tiles) return nullptr;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!base) {
+    PerDevice& d = tab[dev];
+    if (!d.base) {
         void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return nullptr;
-        base = (unsigned*)p;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return nullptr;     // resolves on the current device
+        // zeroed once, synchronously, on first use of this device (a stream that is being captured into a HIP graph refuses the
+        // call: no slot then, and nothing is cached - the engines call unetrir_reset_tile_tickets() when they are built)
+        if (hipMemset(p, 0, sizeof(unsigned) * 128 * 80) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        d.base = (unsigned*)p;
     }
-    for (int i = 0; i < used; ++i) if (owner[i] == s) return base + i * 80;
-    if (used == 128) return nullptr;
-    owner[used] = s;
-    return base + (used++) * 80;
+    for (int i = 0; i < d.used; ++i) if (d.owner[i] == s) return d.base + i * 80;
+    if (d.used == 128) return nullptr;
+    d.owner[d.used] = s;
+    return d.base + (d.used++) * 80;
+}
+
+// Host-side reset of every ticket slot of the current device (after toggling dyn_tiles, or after a launch failed): call with the
+// device idle.  The kernels clear their own slot at the end of every launch, so a healthy run never needs it.
+extern "C" int unetrir_reset_tile_tickets(void) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return UNETRIR_EINVAL;
+    return (int)hipMemset(p, 0, sizeof(unsigned) * 128 * 80);
 }
 
 namespace {

@@ -379,15 +379,19 @@ __global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ x, int B, int 
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
+// phase_ref (nullable): the network INPUT, NCHW - the `diff_loss` switch of main_training.py:214-217 (phase target = phase_true -
+// phase_x).  phase_w (nullable): [W] column weights of the phase term - the `sigmoid_loss` switch (:221-222, preprocess.py:116-121).
+// part: three doubles per block (amplitude sum, phase sum as the metrics see it, phase sum as the loss sees it = weighted).
 template <typename T>
 __global__ __launch_bounds__(256) void sigmoid_loss_kernel(const float* __restrict__ logits, int ldl,
                                                            const float* __restrict__ target, int B, int H, int W,
                                                            float alpha, float inv_norm, float* __restrict__ pred,
-                                                           T* __restrict__ dlogits, int ldd, double* __restrict__ part) {
-    __shared__ double red[256 * 2];
+                                                           T* __restrict__ dlogits, int ldd, double* __restrict__ part,
+                                                           const float* __restrict__ phase_ref, const float* __restrict__ phase_w) {
+    __shared__ double red[256 * 3];
     const long long hw = (long long)H * W, total = (long long)B * hw;
     const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
-    double sa = 0, sp = 0;
+    double sa = 0, sp = 0, spw = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / hw, r = i - b * hw;
@@ -395,33 +399,49 @@ __global__ __launch_bounds__(256) void sigmoid_loss_kernel(const float* __restri
         pred[(b * 2 + 0) * hw + r] = p0;
         pred[(b * 2 + 1) * hw + r] = p1;
         if (target) {
-            const float t0 = target[(b * 2 + 0) * hw + r], t1 = target[(b * 2 + 1) * hw + r];
+            const float t0 = target[(b * 2 + 0) * hw + r];
+            float t1 = target[(b * 2 + 1) * hw + r];
+            if (phase_ref) t1 -= phase_ref[(b * 2 + 1) * hw + r];
+            const float wgt = phase_w ? phase_w[(int)(r % W)] : 1.f;
             const float da = t0 - p0;
             const float yt = t1 * TWO_PI - PI, yp = p1 * TWO_PI - PI;
             const float d = (yt - yp) + PI;
             const float ph = (d - floorf(d / TWO_PI) * TWO_PI) - PI;     // python-style modulo
+            const float eph = 1.f - cosf(ph);
             sa += (double)(da * da);
-            sp += (double)(1.f - cosf(ph));
+            sp += (double)eph;
+            spw += (double)(eph * wgt);
             const float g0 = -2.f * da * alpha * inv_norm;
-            const float g1 = -(1.f - alpha) * inv_norm * TWO_PI * sinf(ph);
+            const float g1 = -(1.f - alpha) * inv_norm * TWO_PI * sinf(ph) * wgt;
             st4(dlogits + i * ldd, make_float4(g0 * p0 * (1.f - p0), g1 * p1 * (1.f - p1), 0.f, 0.f));
             if (ldd > 4) st4(dlogits + i * ldd + 4, make_float4(0.f, 0.f, 0.f, 0.f));
         }
     }
-    red[threadIdx.x * 2] = sa; red[threadIdx.x * 2 + 1] = sp;
+    red[threadIdx.x * 3] = sa; red[threadIdx.x * 3 + 1] = sp; red[threadIdx.x * 3 + 2] = spw;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 256; ++k) { sa += red[k * 2]; sp += red[k * 2 + 1]; }
-        part[blockIdx.x * 2] = sa; part[blockIdx.x * 2 + 1] = sp;
+        for (int k = 1; k < 256; ++k) { sa += red[k * 3]; sp += red[k * 3 + 1]; spw += red[k * 3 + 2]; }
+        part[blockIdx.x * 3] = sa; part[blockIdx.x * 3 + 1] = sp; part[blockIdx.x * 3 + 2] = spw;
     }
 }
 
 __global__ void loss_finalize_kernel(const double* __restrict__ part, int nblk, float alpha, float inv_norm,
                                      float* __restrict__ out) {
-    double sa, sp;
-    slab_sum(part, nblk, 1, 0, sa, sp);
+    __shared__ double red[256 * 3];
+    double a = 0, b = 0, c = 0;
+    for (int k = threadIdx.x; k < nblk; k += 256) { a += part[k * 3]; b += part[k * 3 + 1]; c += part[k * 3 + 2]; }
+    red[threadIdx.x * 3] = a; red[threadIdx.x * 3 + 1] = b; red[threadIdx.x * 3 + 2] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {          // fixed pairing order
+        if (threadIdx.x < st) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) red[threadIdx.x * 3 + j] += red[(threadIdx.x + st) * 3 + j];
+        }
+        __syncthreads();
+    }
     if (threadIdx.x != 0) return;
-    out[0] = (float)(((double)alpha * sa + (1.0 - (double)alpha) * sp) * (double)inv_norm);
+    const double sa = red[0], sp = red[1], spw = red[2];
+    out[0] = (float)(((double)alpha * sa + (1.0 - (double)alpha) * spw) * (double)inv_norm);
     out[1] = (float)sa;
     out[2] = (float)sp;
 }
@@ -541,7 +561,9 @@ __global__ void sumsq_finalize_kernel(const double* __restrict__ part, int nblk,
 // Keras Adam: m,v update; theta -= lr_t * m / (sqrt(v) + eps)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
-                                                   float lr_t, float b1, float b2, float eps, float gs) {
+                                                   float lr_t, float b1, float b2, float eps, float gs,
+                                                   const float* __restrict__ hyper) {
+    if (hyper) { lr_t = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; gs = hyper[4]; }      // step-dependent values from device memory (HIP graphs)
     const long long n4 = n / 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     // two independent 16-byte groups per thread and iteration: 8 loads in flight before the first store
@@ -656,13 +678,14 @@ int relu_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C
 #define LOSS_BLOCKS 1024
 template <typename T>
 int sigmoid_loss_impl(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha, float inv_norm,
-                      float* pred, T* dlogits, int ldd, float* loss_out, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!logits || ldl < 2 || !target || !pred || !dlogits || !loss_out || !ws || ws_bytes < (size_t)LOSS_BLOCKS * 2 * sizeof(double) ||
+                      float* pred, T* dlogits, int ldd, float* loss_out, void* ws, size_t ws_bytes, hipStream_t s,
+                      const float* phase_ref = nullptr, const float* phase_w = nullptr) {
+    if (!logits || ldl < 2 || !target || !pred || !dlogits || !loss_out || !ws || ws_bytes < (size_t)LOSS_BLOCKS * 3 * sizeof(double) ||
         B <= 0 || H <= 0 || W <= 0 || (ldd != 4 && ldd != 8))
         return UNETRIR_EINVAL;
     const unsigned nb = grid_for((long long)B * H * W, 256, LOSS_BLOCKS);
     hipLaunchKernelGGL(sigmoid_loss_kernel<T>, dim3(nb), dim3(256), 0, s, logits, ldl, target, B, H, W, alpha, inv_norm, pred,
-                       dlogits, ldd, (double*)ws);
+                       dlogits, ldd, (double*)ws, phase_ref, phase_w);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)ws, (int)nb, alpha, inv_norm, loss_out);
     return (int)hipGetLastError();
 }
@@ -717,13 +740,20 @@ int unetrir_nchw_to_nhwc_pad_f32(const float* x, int B, int C, int H, int W, flo
     return (int)hipGetLastError();
 }
 
-size_t unetrir_loss_ws_bytes(long long npix) { (void)npix; return (size_t)LOSS_BLOCKS * 2 * sizeof(double); }
+size_t unetrir_loss_ws_bytes(long long npix) { (void)npix; return (size_t)LOSS_BLOCKS * 3 * sizeof(double); }
 
 int unetrir_sigmoid_loss_f32(const float* logits, int ldl, const float* target, int B, int H, int W, float alpha,
                              float inv_norm, float* pred, float* dlogits, float* loss_out, void* ws, size_t ws_bytes,
                              unetrir_stream_t stream) {
     return sigmoid_loss_impl<float>(logits, ldl, target, B, H, W, alpha, inv_norm, pred, dlogits, 4, loss_out, ws, ws_bytes,
                                     (hipStream_t)stream);
+}
+
+int unetrir_sigmoid_loss_ex_f32(const float* logits, int ldl, const float* target, const float* phase_ref, const float* phase_weight,
+                                int B, int H, int W, float alpha, float inv_norm, float* pred, float* dlogits, float* loss_out,
+                                void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    return sigmoid_loss_impl<float>(logits, ldl, target, B, H, W, alpha, inv_norm, pred, dlogits, 4, loss_out, ws, ws_bytes,
+                                    (hipStream_t)stream, phase_ref, phase_weight);
 }
 
 int unetrir_sigmoid_nchw_f32(const float* logits, int ldl, int B, int H, int W, float* pred, unetrir_stream_t stream) {
@@ -777,7 +807,14 @@ int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long
                      float eps, float grad_scale, unetrir_stream_t stream) {
     if (!theta || !g || !m || !v || n <= 0) return UNETRIR_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n,
-                       lr_t, beta1, beta2, eps, grad_scale);
+                       lr_t, beta1, beta2, eps, grad_scale, (const float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int unetrir_adam_dev_f32(float* theta, const float* g, float* m, float* v, long long n, const float* hyper, unetrir_stream_t stream) {
+    if (!theta || !g || !m || !v || !hyper || n <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n,
+                       0.f, 0.f, 0.f, 0.f, 0.f, hyper);
     return (int)hipGetLastError();
 }
 
@@ -913,6 +950,13 @@ int unetrir_sigmoid_loss_bf16(const float* logits, int ldl, const float* target,
                                      (hipStream_t)stream);
 }
 
+int unetrir_sigmoid_loss_ex_bf16(const float* logits, int ldl, const float* target, const float* phase_ref, const float* phase_weight,
+                                 int B, int H, int W, float alpha, float inv_norm, float* pred, unetrir_bf16* dlogits, float* loss_out,
+                                 void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    return sigmoid_loss_impl<__bf16>(logits, ldl, target, B, H, W, alpha, inv_norm, pred, (__bf16*)dlogits, 8, loss_out, ws, ws_bytes,
+                                     (hipStream_t)stream, phase_ref, phase_weight);
+}
+
 int unetrir_sigmoid_bwd_bf16(const float* pred, const float* dpred, int B, int H, int W, unetrir_bf16* dlogits,
                              unetrir_stream_t stream) {
     if (!pred || !dpred || !dlogits || B <= 0 || H <= 0 || W <= 0) return UNETRIR_EINVAL;
@@ -981,13 +1025,31 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 }
 
 __global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, float p, float keep_scale, unsigned long long seed,
-                                    unsigned long long step) {
+                                    unsigned long long step, const unsigned long long* __restrict__ step_dev) {
+    if (step_dev) step += *step_dev;          // draw number from device memory (a captured HIP graph replays the same arguments)
     const unsigned long long key = mix64(seed * 0x9E3779B97F4A7C15ULL + step);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const unsigned long long r = mix64(key + 0x9E3779B97F4A7C15ULL * (unsigned long long)(i + 1));
         const float u = (float)(r >> 40) * (1.0f / 16777216.0f);          // 24 bits -> [0, 1)
         mask[i] = (u >= p) ? keep_scale : 0.f;
     }
+}
+
+// Step counters kept in device memory so that a captured HIP graph can be replayed unchanged: state[0] = Adam step count t,
+// state[1] = dropout draws made so far, state[2] = first draw of the CURRENT step (what unetrir_dropout_mask_dev_f32 reads).
+// cfg = {lr, beta1, beta2, eps, grad_scale} as the host last set them; hyper = the same with lr replaced by
+// lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) for the step that begins (main_training.py:168-169, :268).
+__global__ void step_advance_kernel(unsigned long long* __restrict__ state, const float* __restrict__ cfg, float* __restrict__ hyper,
+                                    int n_draws, int advance_t) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long t = state[0] + (advance_t ? 1ull : 0ull);      // advance_t == 0: a forward-only pass (validation) draws masks too
+    state[0] = t;
+    const double b1 = (double)cfg[1], b2 = (double)cfg[2];
+    hyper[0] = (float)((double)cfg[0] * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+    hyper[1] = cfg[1]; hyper[2] = cfg[2]; hyper[3] = cfg[3]; hyper[4] = cfg[4];
+    const unsigned long long d = state[1];
+    state[2] = d;
+    state[1] = d + (unsigned long long)n_draws;
 }
 
 __global__ void index_to_i32_kernel(const void* __restrict__ idx, int elem_bytes, long long n, int* __restrict__ out) {
@@ -1008,7 +1070,22 @@ int unetrir_bn_inference_affine_f32(const float* gamma, const float* beta, const
 int unetrir_dropout_mask_f32(float* mask, long long n, float p, unsigned long long seed, unsigned long long step,
                              unetrir_stream_t stream) {
     if (!mask || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p, 1.f / (1.f - p), seed, step);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p, 1.f / (1.f - p), seed, step,
+                       (const unsigned long long*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int unetrir_dropout_mask_dev_f32(float* mask, long long n, float p, unsigned long long seed, const unsigned long long* step_base,
+                                 unsigned long long step_offset, unetrir_stream_t stream) {
+    if (!mask || !step_base || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p, 1.f / (1.f - p), seed,
+                       step_offset, step_base);           // draw number = *step_base + step_offset
+    return (int)hipGetLastError();
+}
+
+int unetrir_step_advance(unsigned long long* state, const float* cfg, float* hyper, int n_draws, int advance_t, unetrir_stream_t stream) {
+    if (!state || !cfg || !hyper || n_draws < 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, cfg, hyper, n_draws, advance_t);
     return (int)hipGetLastError();
 }
 

@@ -108,7 +108,111 @@ class _SideStream:
         return False
 
 
-class UNetEngine:
+class DeviceCounters:
+    """Mixin of the engines: the per-step scalars (Adam's bias-corrected rate, the dropout draw number) either travel as launch
+    arguments computed on the host (default) or live in DEVICE memory, advanced by one tiny kernel at the start of every step
+    (`use_device_counters()`): a step then consists of the same launches with the same arguments every time and can be captured
+    once into a HIP graph and replayed (trainer.Trainer(graph=True)).  The host mirrors (`adam_t`, `dropout_step`) are kept in
+    step either way; checkpoints hold the host values."""
+    n_dropout_draws = 1          # dropout masks drawn per step
+    # compute_loss switches (main_training.py:38-39, :214-222); set through trainer.Trainer(sigmoid_loss=, diff_loss=, beta=)
+    loss_diff = False            # diff_loss: the phase target is phase_true - phase of the network input
+    loss_phase_weight = None     # sigmoid_loss: fp32 [W] column weights of the phase term (device tensor)
+    _last_spec = None            # the input of the last forward pass (diff_loss through loss_from_logits)
+
+    def _loss_extras(self, spec=None):
+        if spec is not None:
+            self._last_spec = spec
+        ref = self._last_spec if self.loss_diff else None
+        if self.loss_diff and ref is None:
+            raise RuntimeError("diff_loss needs the network input of the last forward pass")
+        return {"phase_ref": ref, "phase_weight": self.loss_phase_weight}
+
+    def use_device_counters(self, on=True):
+        dev = self._shared.get("dev")
+        if not on:
+            if dev is not None:
+                dev["on"] = False          # the tensors stay alive: a captured graph may still reference them
+            return
+        if dev is None:
+            dev = self._shared["dev"] = {"state": torch.zeros(3, dtype=torch.int64, device=self.device),
+                                         "cfg": torch.zeros(8, dtype=torch.float32, device=self.device),
+                                         "hyper": torch.zeros(8, dtype=torch.float32, device=self.device), "cfg_host": None, "offset": 0,
+                                         "on": False}
+        if not dev["on"]:
+            dev["on"] = True
+            self.sync_device_counters()
+
+    def _dev(self):
+        dev = self._shared.get("dev")
+        return dev if (dev is not None and dev["on"]) else None
+
+    def sync_device_counters(self):
+        """Host counters -> device (when the mode is switched on, after reset_parameters, after a restored checkpoint)."""
+        dev = self._dev()
+        if dev is not None:
+            dev["state"].copy_(torch.tensor([self.adam_t, self._shared["dropout_step"], self._shared["dropout_step"]], dtype=torch.int64))
+
+    @property
+    def device_counters(self):
+        return self._dev()
+
+    def begin_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, n_draws=None, forward_only=False):
+        """Device counters only: the launch that opens a step (before the dropout masks are drawn; n_draws of them, default
+        n_dropout_draws).  forward_only: a pass without an optimizer step (validation) - the Adam step count stays."""
+        dev = self._dev()
+        if dev is None:
+            return
+        self.set_step_cfg(lr, beta1, beta2, eps, grad_scale)
+        ops.step_advance(dev["state"], dev["cfg"], dev["hyper"], self.n_dropout_draws if n_draws is None else n_draws, not forward_only)
+        dev["offset"] = 0
+
+    def set_step_cfg(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """Device counters only: the optimizer's scalars as the next step_advance launch reads them.  Copies only when a value
+        changed (the rate changes once per epoch, main_training.py:342-344): a blocking 20-byte transfer, outside any graph."""
+        dev = self._dev()
+        cfg = (float(lr), beta1, beta2, eps, float(grad_scale))
+        if dev is not None and dev["cfg_host"] != cfg:
+            dev["cfg"][:5].copy_(torch.tensor(cfg, dtype=torch.float32))
+            dev["cfg_host"] = cfg
+
+    def _draw_mask(self, buf):
+        """Fill `buf` with the next keep mask of this engine's dropout stream."""
+        dev = self._dev()
+        if dev is None:
+            ops.dropout_mask(buf, DROPOUT_P, self.dropout_seed, self._shared["dropout_step"])
+        else:
+            ops.dropout_mask_dev(buf, DROPOUT_P, self.dropout_seed, dev["state"], dev["offset"])
+            dev["offset"] += 1
+        self._shared["dropout_step"] += 1
+        return buf
+
+    def _adam(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
+        dev = self._dev()
+        th, g, m, v = (self.theta, self.grad, self.adam_m, self.adam_v) if lo is None else \
+            (self.theta[lo:hi], self.grad[lo:hi], self.adam_m[lo:hi], self.adam_v[lo:hi])
+        if dev is None:
+            ops.adam(th, g, m, v, lr_t, beta1, beta2, eps, grad_scale)
+        else:
+            ops.adam_dev(th, g, m, v, dev["hyper"])
+        self.t_dirty = True
+
+    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """tf.keras Adam over the whole flat parameter buffer in one launch (main_training.py:268)."""
+        self._adam(None, None, *self.adam_begin(lr, beta1, beta2, eps, grad_scale))
+
+    def adam_begin(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        """Advance the step count once and return the arguments of adam_range for this step (bucket-wise optimizer)."""
+        self.adam_t += 1
+        t = self.adam_t
+        return (lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t), beta1, beta2, eps, grad_scale)
+
+    def adam_range(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
+        """Adam on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
+        self._adam(lo, hi, lr_t, beta1, beta2, eps, grad_scale)
+
+
+class UNetEngine(DeviceCounters):
     """One replica of the model for a fixed per-replica batch size B on one device."""
     mask_on_side_stream = True       # the dropout mask's only consumers (information-vector branch) run on the side stream
 
@@ -580,6 +684,8 @@ class UNetEngine:
             self.refresh_transposed()
         if emb.dtype not in (torch.int32, torch.int64):
             emb = emb.to(torch.int64)
+        if emb.device != self.device:      # DataGenerator.__getitem__ hands over host arrays: a small copy, never a host pointer
+            emb = emb.to(self.device)
         ops.index_to_i32(emb.contiguous(), self.emb_idx)
         self.dropout_mask = dropout_mask
 
@@ -631,8 +737,9 @@ class UNetEngine:
         if target is not None:
             gb = B if global_batch is None else global_batch
             inv_norm = 1.0 / (2.0 * self.H * self.W * gb)
-            ops.sigmoid_loss(self.logits, target, alpha, inv_norm, self.pred, self.g_logits, self.loss_out, self.ws)
+            ops.sigmoid_loss(self.logits, target, alpha, inv_norm, self.pred, self.g_logits, self.loss_out, self.ws, **self._loss_extras(spec))
         else:
+            self._last_spec = spec
             ops.sigmoid_nchw(self.logits, self.pred)
         return self.pred
 
@@ -652,7 +759,8 @@ class UNetEngine:
         gb = self.B if global_batch is None else global_batch
         if tuple(target.shape) != (self.B, 2, self.H, self.W) or target.dtype != torch.float32 or not target.is_contiguous():
             raise ValueError(f"target must be a contiguous float32 [{self.B},2,{self.H},{self.W}] tensor")
-        ops.sigmoid_loss(self.logits, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, self.g_logits, self.loss_out, self.ws)
+        ops.sigmoid_loss(self.logits, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, self.g_logits, self.loss_out, self.ws,
+                         **self._loss_extras())
 
     def loss_total(self):
         """Data loss + l2 terms as one device scalar (a 4-byte copy and the l2 reductions accumulating onto it)."""
@@ -804,26 +912,7 @@ class UNetEngine:
         if self.wg_stream is not None:
             self.rt.wait(self.rt.current_stream(), self.rt.record(self.wg_stream))
 
-    # ------------------------------------------------------------------ optimizer
-    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-        """tf.keras Adam over the whole flat parameter buffer in one launch (main_training.py:268)."""
-        self.adam_t += 1
-        t = self.adam_t
-        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-        ops.adam(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, beta1, beta2, eps, grad_scale)
-        self.t_dirty = True
-
-    def adam_begin(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-        """Advance the step count once and return the arguments of adam_range for this step (bucket-wise optimizer)."""
-        self.adam_t += 1
-        t = self.adam_t
-        return (lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t), beta1, beta2, eps, grad_scale)
-
-    def adam_range(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
-        """Adam on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
-        ops.adam(self.theta[lo:hi], self.grad[lo:hi], self.adam_m[lo:hi], self.adam_v[lo:hi], lr_t, beta1, beta2, eps, grad_scale)
-        self.t_dirty = True
-
+    # ------------------------------------------------------------------ optimizer: DeviceCounters.adam_step / adam_begin / adam_range
     def make_dropout_mask(self, generator=None):
         """Keep mask of Dropout(.3) scaled by 1/(1-p), [B, vec_dim].  Default: the HIP generator kernel, draw number
         `dropout_step` of stream `dropout_seed` (reproducible; the trainer offsets the seed by the replica rank), written
@@ -833,9 +922,7 @@ class UNetEngine:
             return keep.to(torch.float32) / (1.0 - DROPOUT_P)
         if self._mask_buf is None:
             self._mask_buf = torch.empty((self.B, self.vec_dim), dtype=torch.float32, device=self.device)
-        ops.dropout_mask(self._mask_buf, DROPOUT_P, self.dropout_seed, self._shared["dropout_step"])
-        self._shared["dropout_step"] += 1
-        return self._mask_buf
+        return self._draw_mask(self._mask_buf)
 
     def n_params(self):
         """Trainable parameter count in the reference's sense (padding excluded)."""

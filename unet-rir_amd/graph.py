@@ -18,7 +18,7 @@ import torch
 from . import ops
 from .device import HipRuntime
 from .ops import Act
-from .engine import ALIGN, BN_EPS, BN_MOMENTUM, L2_COEF, DROPOUT_P, ParamSpec, _SideStream
+from .engine import ALIGN, BN_EPS, BN_MOMENTUM, L2_COEF, DROPOUT_P, DeviceCounters, ParamSpec, _SideStream
 
 RELU, LEAKY = 1, 2       # activation codes of the C ABI (LeakyReLU: keras default alpha 0.3)
 
@@ -35,7 +35,7 @@ class Node:
         self.children = []           # channel-slice views: written whenever this node's gradient is written
 
 
-class GraphEngine:
+class GraphEngine(DeviceCounters):
     mask_on_side_stream = False      # the dropout masks are consumed by nodes of the main stream (trainer.Trainer._make_mask)
 
     def __init__(self, B, device="cuda:0", n_replicas=1, runtime=None, share=None, dtype="f32", overlap_wgrad=False):
@@ -375,6 +375,8 @@ class GraphEngine:
     def set_indices(self, emb):
         if emb.dtype not in (torch.int32, torch.int64):
             emb = emb.to(torch.int64)
+        if emb.device != self.device:      # host arrays from a DataGenerator: a small copy, never a host pointer to the kernel
+            emb = emb.to(self.device)
         ops.index_to_i32(emb.contiguous(), self.emb_idx)
 
     def _reshape(self, x: Node, h, w, c):
@@ -570,7 +572,8 @@ class GraphEngine:
             la = self._logits32
         if target is not None:
             gb = self.B if global_batch is None else global_batch
-            ops.sigmoid_loss(la, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, logits.g, self.loss_out, self.ws)
+            ops.sigmoid_loss(la, target, alpha, 1.0 / (2.0 * self.H * self.W * gb), self.pred, logits.g, self.loss_out, self.ws,
+                             **self._loss_extras())
             logits.g_set = True
         else:
             ops.sigmoid_nchw(la, self.pred)
@@ -607,24 +610,6 @@ class GraphEngine:
             out.zero_()
         return out
 
-    def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7):
-        self.adam_t += 1
-        t = self.adam_t
-        ops.adam(self.theta, self.grad, self.adam_m, self.adam_v, lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t),
-                 beta1, beta2, eps, 1.0)
-        self.t_dirty = True
-
-    def adam_begin(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-        """Advance the step count once and return the arguments of adam_range for this step (bucket-wise optimizer)."""
-        self.adam_t += 1
-        t = self.adam_t
-        return (lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t), beta1, beta2, eps, grad_scale)
-
-    def adam_range(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
-        """Adam on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
-        ops.adam(self.theta[lo:hi], self.grad[lo:hi], self.adam_m[lo:hi], self.adam_v[lo:hi], lr_t, beta1, beta2, eps, grad_scale)
-        self.t_dirty = True
-
     def dropout_mask(self, n, generator=None, slot=0):
         """Keep mask [B, n] of Dropout(.3) scaled by 1/(1-p): HIP generator kernel into a reused buffer per `slot`, or torch's
         generator when one is passed (tests)."""
@@ -633,9 +618,7 @@ class GraphEngine:
         buf = self._mask_bufs.get(slot)
         if buf is None or buf.shape[1] != n:
             buf = self._mask_bufs[slot] = torch.empty((self.B, n), dtype=torch.float32, device=self.device)
-        ops.dropout_mask(buf, DROPOUT_P, self.dropout_seed, self._shared["dropout_step"])
-        self._shared["dropout_step"] += 1
-        return buf
+        return self._draw_mask(buf)
 
     def n_params(self):
         return sum(int(math.prod(s_.keras_shape)) for s_ in self.specs.values())

@@ -198,6 +198,7 @@ class _EngineModule(nn.Module):
         if v != self._seen_version:          # an optimizer step / load_state_dict wrote the parameters in place
             eng.t_dirty = True
             self._seen_version = v
+        eng.use_device_counters(False)       # this path passes its per-step scalars as launch arguments (trainer.Trainer(graph=True) does not)
         if dropout_mask is None and self.training and self.dropout:
             dropout_mask = eng.make_dropout_mask()
         spec = spec.to(self._device, torch.float32).contiguous()
@@ -313,11 +314,13 @@ class _SubModel:
                 spec, emb = inputs
                 eng = m._engine_for(spec.shape[0])
                 eng.training = training
+                eng.use_device_counters(False)
                 mask = eng.make_dropout_mask() if (training and m.dropout) else None
                 return eng.encode(spec.permute(0, 3, 1, 2).to(m._device, torch.float32).contiguous(), emb.to(m._device), mask)
             z = inputs
             eng = m._engine_for(z.shape[0])
             eng.training = training
+            eng.use_device_counters(False)
             mask = eng.make_dropout_mask() if (training and m.dropout) else None
             return eng.decode(z.to(m._device, torch.float32).contiguous(), mask).permute(0, 2, 3, 1)
 

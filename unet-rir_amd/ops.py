@@ -410,12 +410,25 @@ def istft_features(feat, wav, n_bins, n_frames, n_fft=256, win_length=128, hop_l
                                                 int(denormalize), _p(wav), _stream()), "istft_features")
 
 
-def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_out, ws: Workspace):
-    """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits."""
+def sigmoid_loss(logits: Act, target, alpha, inv_norm, pred, dlogits: Act, loss_out, ws: Workspace, phase_ref=None, phase_weight=None):
+    """sigmoid head (dl_models/u_net.py:249) + compute_loss (main_training.py:203-231) + dL/dlogits.
+    phase_ref: the network input [B,2,H,W] (the `diff_loss` switch, main_training.py:214-217); phase_weight: fp32 [W] column
+    weights of the phase term (the `sigmoid_loss` switch, :221-222)."""
     B, _, H, W = target.shape
     ws.reserve(_lib.lib().unetrir_loss_ws_bytes(B * H * W))
-    check(_fn("sigmoid_loss", dlogits.sfx)(_p(logits), logits.ld, _p(target), B, H, W, alpha, inv_norm, _p(pred),
-                                           _p(dlogits), _p(loss_out), ws.ptr, ws.nbytes, _stream()), "sigmoid_loss")
+    if phase_ref is None and phase_weight is None:
+        check(_fn("sigmoid_loss", dlogits.sfx)(_p(logits), logits.ld, _p(target), B, H, W, alpha, inv_norm, _p(pred),
+                                               _p(dlogits), _p(loss_out), ws.ptr, ws.nbytes, _stream()), "sigmoid_loss")
+        return
+    if phase_ref is not None and (tuple(phase_ref.shape) != tuple(target.shape) or phase_ref.dtype != torch.float32 or
+                                  not phase_ref.is_contiguous() or phase_ref.device != target.device):
+        raise ValueError("phase_ref must be a contiguous float32 tensor of the target's shape on the same device")
+    if phase_weight is not None and (tuple(phase_weight.shape) != (W,) or phase_weight.dtype != torch.float32 or
+                                     phase_weight.device != target.device):
+        raise ValueError(f"phase_weight must be float32 [{W}] on the target's device")
+    check(_fn("sigmoid_loss_ex", dlogits.sfx)(_p(logits), logits.ld, _p(target), _p(phase_ref), _p(phase_weight), B, H, W, alpha,
+                                              inv_norm, _p(pred), _p(dlogits), _p(loss_out), ws.ptr, ws.nbytes, _stream()),
+          "sigmoid_loss_ex")
 
 
 def sigmoid_nchw(logits: Act, pred):
@@ -449,6 +462,8 @@ def index_to_i32(idx, out):
     """int32 / int64 index tensor -> the int32 array the embedding kernels read."""
     if idx.dtype not in (torch.int32, torch.int64) or not idx.is_contiguous() or idx.numel() != out.numel():
         raise ValueError("indices must be a contiguous int32 or int64 tensor of the expected size")
+    if idx.device != out.device:      # a host pointer handed to the kernel is a GPU memory fault, not an exception
+        raise ValueError(f"indices live on {idx.device}, the engine on {out.device}")
     check(_lib.lib().unetrir_index_to_i32(_p(idx), idx.element_size(), idx.numel(), _p(out), _stream()), "index_to_i32")
 
 
@@ -466,6 +481,27 @@ def adam(theta, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0)
     """tf.keras.optimizers.Adam step over a flat buffer (main_training.py:168-169, :268)."""
     check(_lib.lib().unetrir_adam_f32(_p(theta), _p(g), _p(m), _p(v), theta.numel(), float(lr_t), beta1, beta2, eps,
                                       float(grad_scale), _stream()), "adam")
+
+
+def adam_dev(theta, g, m, v, hyper):
+    """adam() with its five scalars read from device memory (hyper: fp32 [>=5], written by step_advance): HIP-graph replay."""
+    check(_lib.lib().unetrir_adam_dev_f32(_p(theta), _p(g), _p(m), _p(v), theta.numel(), _p(hyper), _stream()), "adam_dev")
+
+
+def dropout_mask_dev(mask, p, seed, state, offset):
+    """dropout_mask() with draw number state[2] + offset read from device memory (state: the uint64 [3] of step_advance)."""
+    check(_lib.lib().unetrir_dropout_mask_dev_f32(_p(mask), mask.numel(), float(p), int(seed), C.c_void_p(state.data_ptr() + 16),
+                                                  int(offset), _stream()), "dropout_mask_dev")
+
+
+def step_advance(state, cfg, hyper, n_draws, advance_t=True):
+    """Start of a step whose counters live in device memory: t += 1, hyper = (lr_t, beta1, beta2, eps, grad_scale), draw base.
+    advance_t=False: a forward-only pass (the validation loop draws dropout masks, main_training.py:297-300)."""
+    check(_lib.lib().unetrir_step_advance(_p(state), _p(cfg), _p(hyper), int(n_draws), int(bool(advance_t)), _stream()), "step_advance")
+
+
+def reset_tile_tickets():
+    check(_lib.lib().unetrir_reset_tile_tickets(), "reset_tile_tickets")
 
 
 # ---- kernel-selection switches --------------------------------------------------------------------

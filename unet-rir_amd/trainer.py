@@ -81,6 +81,13 @@ class GradBucketer:
         self.sent = 0
 
 
+def phase_weight(beta, W):
+    """preprocess.sigmoid(beta, (H, W)) (preprocess.py:116-121): every row of the mask the `sigmoid_loss` switch multiplies into
+    the phase term is z = 1 / (1 + exp(-(x + 5) beta)) on x = linspace(-10, 10, W), flipped.  fp32 [W]."""
+    x = torch.linspace(-10.0, 10.0, W, dtype=torch.float64)
+    return torch.flip(1.0 / (1.0 + torch.exp(-(x + 5.0) * beta)), dims=(0,)).to(torch.float32)
+
+
 def lr_schedule(lr0, epoch, decay=(True, 80)):
     """main_training.py:342-344: from epoch >= 80 the rate is lr0 * 0.9 ** (epoch / 80)."""
     if decay and decay[0] and epoch >= decay[1]:
@@ -118,8 +125,17 @@ class Trainer:
       trainer.apply_gradients()                                  #   optimizer.apply_gradients
     """
 
-    def __init__(self, model, lr=5e-7, alpha=0.9, world_size=1, group=None, bucket_bytes=32 << 20, dropout=True, force_dp=False):
-        """force_dp: run the bucketed all-reduce path even at world_size 1 (needs an initialised process group; rehearsal)."""
+    def __init__(self, model, lr=5e-7, alpha=0.9, world_size=1, group=None, bucket_bytes=32 << 20, dropout=True, force_dp=False,
+                 sigmoid_loss=False, diff_loss=False, beta=0.5, graph=False, dropout_seed=None):
+        """force_dp: run the bucketed all-reduce path even at world_size 1 (needs an initialised process group; rehearsal).
+        sigmoid_loss / diff_loss / beta: the switches of compute_loss (main_training.py:38-40, :214-222; both False in the
+        reference's live configuration): column weights sigmoid(beta, ...) of preprocess.py:116-121 on the phase term, and the
+        phase target taken relative to the input's phase.
+        graph: capture `step` once into a HIP graph (after one ordinary step that is undone) and replay it - one host call per
+        step instead of several hundred launches; single-replica steps without an externally supplied dropout mask only
+        (anything else runs the ordinary way).
+        dropout_seed: base seed of the Dropout streams; replica r draws from stream seed + r (independent masks per replica, as
+        under MirroredStrategy).  Default: the engine's own seed (torch.initial_seed())."""
         self.module = None
         engine = model
         if not hasattr(model, "specs") and hasattr(model, "engine"):
@@ -136,6 +152,17 @@ class Trainer:
         self.bucketer = None
         engine.n_replicas = world_size
         dp = world_size > 1 or (force_dp and dist.is_initialized())
+        # per-replica Dropout streams: the engine's seed is process-wide (torch.initial_seed()), identical in every rank
+        if dropout_seed is not None:
+            engine.dropout_seed = int(dropout_seed) & 0xFFFFFFFF
+        self.rank = dist.get_rank(group) if (world_size > 1 and dist.is_initialized()) else 0
+        if world_size > 1 and not getattr(engine, "_seed_offset_by_rank", False):
+            engine.dropout_seed = (engine.dropout_seed + self.rank) & 0xFFFFFFFF
+            engine._seed_offset_by_rank = True
+        engine.loss_diff = bool(diff_loss)
+        engine.loss_phase_weight = phase_weight(beta, engine.W).to(engine.device) if sigmoid_loss else None
+        self.use_graph = bool(graph) and not dp
+        self._graphs, self._g_in = {}, None
         # With a side stream in the engine (overlap_wgrad) the optimizer also leaves the critical path: Adam runs bucket by
         # bucket on a third stream as soon as a bucket's gradients are final (and, data-parallel, all-reduced), while the
         # backward pass continues.  A finished bucket's parameters are never read again by that backward pass.
@@ -201,33 +228,99 @@ class Trainer:
         eng = self.engine
         side = getattr(eng, "wg_stream", None) if getattr(eng, "mask_on_side_stream", False) else None
         if side is not None:       # its only consumers (the information-vector branch, forward and backward) run on that stream
+            if eng.device_counters is not None:          # the draw number comes from the step_advance launch of the main stream
+                self.rt.wait(side, self.rt.record())
             with self.rt.on(side):
                 return eng.make_dropout_mask()
         return eng.make_dropout_mask()
+
+    def _step_body(self, spec_in, emb, spec_out, dropout_mask, with_reg):
+        """The launches of one step (what a HIP graph captures)."""
+        eng = self.engine
+        eng.begin_step(self._lr_now, n_draws=eng.n_dropout_draws if (dropout_mask is None and self.dropout) else 0)     # device counters only
+        if dropout_mask is None and self.dropout:
+            dropout_mask = self._make_mask()
+        gb = eng.B * self.world_size
+        eng.forward(spec_in, emb, dropout_mask=dropout_mask, target=spec_out, global_batch=gb, alpha=self.alpha)
+        if with_reg:
+            eng.reg_loss()                      # on the pre-update weights, as compute_loss sees them
+        self._backward_and_reduce()
+        self.apply_gradients()
 
     def step(self, spec_in, emb, spec_out, dropout_mask=None, lr=None, return_loss=False):
         """inputs as DataGenerator.__getitem__ yields them (datageneratorv2.py:101-102), NCHW, per-replica shard."""
         eng = self.engine
         eng.training = True
         self._total_on_device = False
-        if dropout_mask is None and self.dropout:
-            dropout_mask = self._make_mask()
-        gb = eng.B * self.world_size
-        eng.forward(spec_in, emb, dropout_mask=dropout_mask, target=spec_out, global_batch=gb, alpha=self.alpha)
-        if return_loss:
-            eng.reg_loss()                      # on the pre-update weights, as compute_loss sees them
         self._lr_now = self.lr if lr is None else lr
-        self._backward_and_reduce()
-        self.apply_gradients()
+        if self.use_graph and dropout_mask is None:
+            self._graph_step(spec_in, emb, spec_out, bool(return_loss))
+        else:
+            if self.use_graph:
+                eng.use_device_counters(False)     # e.g. an externally supplied mask: launch arguments from the host again
+            self._step_body(spec_in, emb, spec_out, dropout_mask, return_loss)
         if return_loss:
             return self.last_loss()
         return None
+
+    # ---- the step as a HIP graph
+    def _snapshot(self):
+        eng = self.engine
+        return {"theta": eng.theta.clone(), "m": eng.adam_m.clone(), "v": eng.adam_v.clone(), "adam_t": eng.adam_t,
+                "moving": {k: v.clone() for k, v in eng.moving.items()}, "dropout_step": eng._shared["dropout_step"]}
+
+    def _restore(self, snap):
+        eng = self.engine
+        eng.theta.copy_(snap["theta"]); eng.adam_m.copy_(snap["m"]); eng.adam_v.copy_(snap["v"])
+        for k, v in snap["moving"].items():
+            eng.moving[k].copy_(v)
+        eng.adam_t = snap["adam_t"]
+        eng._shared["dropout_step"] = snap["dropout_step"]
+        eng.t_dirty = True
+        eng.sync_device_counters()
+
+    def _graph_step(self, spec_in, emb, spec_out, with_reg):
+        """Replay the captured step on copies of the inputs.  First call (per variant: with / without the l2 terms of the reported
+        loss): one ordinary step with the counters in device memory - every lazily created buffer, table and workspace then
+        exists - undone from a snapshot, then the capture."""
+        eng, rt = self.engine, self.rt
+        eng.use_device_counters(True)          # (re-)synchronises the device counters when another path ran in between
+        if self._g_in is None:
+            if emb.dtype not in (torch.int32, torch.int64):
+                emb = emb.to(torch.int64)
+            self._g_in = (spec_in.to(eng.device, torch.float32).contiguous().clone(), emb.to(eng.device).contiguous().clone(),
+                          spec_out.to(eng.device, torch.float32).contiguous().clone())
+        for dst, src in zip(self._g_in, (spec_in, emb, spec_out)):
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"graph step: input shape {tuple(src.shape)} differs from the captured {tuple(dst.shape)}")
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        eng.set_step_cfg(self._lr_now)
+        g = self._graphs.get(with_reg)
+        if g is None:
+            snap = self._snapshot()
+            self._step_body(*self._g_in, None, with_reg)
+            rt.synchronize()
+            self._restore(snap)
+            rt.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self._step_body(*self._g_in, None, with_reg)
+            # the capture pass advanced the host mirrors as a step does, but ran nothing: undo it on the host only
+            eng.adam_t = snap["adam_t"]
+            eng._shared["dropout_step"] = snap["dropout_step"]
+            self._graphs[with_reg] = g
+        g.replay()
+        eng.adam_t += 1                          # host mirrors of the device counters
+        eng._shared["dropout_step"] += eng.n_dropout_draws if self.dropout else 0
+        eng.t_dirty = True
 
     def compute_loss(self, y_true, y_pred, lr=None):
         """compute_loss(spec_out, spec_generated, model.model.losses) of main_training.py:203-235 for the prediction the model has
         just produced (`y_pred` must be the output of the last forward call of this trainer's model: NHWC from `model.model(...)`
         or NCHW from `model(...)`).  Returns a differentiable 0-dim tensor: data term / global batch + l2 terms / replicas."""
         eng = self.engine
+        eng.use_device_counters(False)             # the module path passes its per-step scalars as launch arguments
         if y_pred.data_ptr() != eng.pred.data_ptr():
             raise ValueError("compute_loss needs the prediction of the model's last forward pass (its own output buffer)")
         tgt = y_true
@@ -281,6 +374,7 @@ class CheckpointManager:
         path = os.path.join(self.directory, f"ckpt-{n}.pt")
         state = {
             "format": 1, "epoch": epoch, "lr": self.trainer.lr, "adam_t": eng.adam_t,
+            "dropout_step": int(eng._shared["dropout_step"]), "dropout_seed": int(eng.dropout_seed),
             "layout": [(k, tuple(s_.shape), int(s_.offset)) for k, s_ in eng.specs.items()],
             "theta": eng.theta.detach().cpu(), "adam_m": eng.adam_m.detach().cpu(), "adam_v": eng.adam_v.detach().cpu(),
             "moving": {k: v.detach().cpu() for k, v in eng.moving.items()},
@@ -306,7 +400,11 @@ class CheckpointManager:
         for k, v in state["moving"].items():
             eng.moving[k].copy_(v)
         eng.adam_t = int(state["adam_t"])
+        if "dropout_step" in state:              # the Dropout stream continues where it stopped (older checkpoints: from draw 0)
+            eng._shared["dropout_step"] = int(state["dropout_step"])
+            eng.dropout_seed = int(state["dropout_seed"])
         eng.t_dirty = True
+        eng.sync_device_counters()
         return state.get("epoch")
 
 
@@ -330,33 +428,36 @@ def fit(trainer: "Trainer", train_batches, n_epochs, val_batches=None, manager: 
     def reduce_(t):
         if trainer.world_size > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=trainer.group)
-        return t.double().cpu()
+        return t.cpu()
 
     for epoch in range(start_epoch, n_epochs):
         lr = lr_schedule(lr0, epoch, lr_exp_decay)
-        tot = torch.zeros(4, dtype=torch.float32, device=eng.device)      # data loss, amplitude sum, phase sum, l2 terms
+        tot = torch.zeros(4, dtype=torch.float64, device=eng.device)      # data loss, amplitude sum, phase sum, l2 terms
         nb = 0
+        eng.reg_loss()
+        reg0 = eng.reg_out[0].double()           # l2 terms on the weights the first step of the epoch sees
         for spec_in, emb, spec_out in train_batches(epoch):
             trainer.step(spec_in, emb, spec_out, lr=lr)
-            tot[:3] += eng.loss_out[:3]          # total data loss, amplitude term, phase term of this step
+            tot[:3] += eng.loss_out[:3].double()     # total data loss, amplitude term, phase term of this step (raw sums ~1e5: fp64)
             nb += 1
-        # the l2 terms at the end of the epoch stand for every step's (they move by lr * 2e-3 * w per step: below fp32 resolution
-        # of the reported mean); evaluated once instead of 9 reductions per step
+        # the l2 terms drift over an epoch (Adam moves every weight by ~lr per step whatever the gradient's scale): the reported
+        # mean takes the trapezoid of their value before the first and after the last step instead of nine reductions per step
         eng.reg_loss()
-        tot[3] = eng.reg_out[0] * max(nb, 1)
+        tot[3] = 0.5 * (reg0 + eng.reg_out[0].double()) * max(nb, 1)
         tot = reduce_(tot)
         n = max(nb, 1)
         rec = {"epoch": epoch + 1, "lr": lr, "train_loss": float(tot[0] + tot[3]) / n,
                "train_amp": float(tot[1]) * per_elem / n, "train_phase": float(tot[2]) * per_elem / n}
         if val_batches is not None:
-            vt = torch.zeros(3, dtype=torch.float32, device=eng.device)
+            vt = torch.zeros(3, dtype=torch.float64, device=eng.device)
             vb = 0
             saved_moving = None if val_updates_moving else {k: v.clone() for k, v in eng.moving.items()}
             for spec_in, emb, spec_out in val_batches(epoch):
                 eng.training = True
+                eng.begin_step(lr, n_draws=eng.n_dropout_draws if trainer.dropout else 0, forward_only=True)     # device counters only
                 mask = eng.make_dropout_mask() if trainer.dropout else None
                 eng.forward(spec_in, emb, dropout_mask=mask, target=spec_out, global_batch=eng.B * trainer.world_size, alpha=trainer.alpha)
-                vt += eng.loss_out[:3]
+                vt += eng.loss_out[:3].double()
                 vb += 1
             if saved_moving is not None:
                 for k, v in saved_moving.items():

@@ -95,6 +95,7 @@ class UNetGraphEngine(GraphEngine):
             raise ValueError(f"spec must be a contiguous float32 [{B},2,{self.H},{self.W}] tensor")
         self.set_indices(emb)
         self.masks["vec"] = dropout_mask
+        self._last_spec = spec
         ops.nchw_to_nhwc_pad(spec, self.x4.a)
         self.run_forward()
         return self.loss_or_sigmoid(self.logits, target, global_batch, alpha)
