@@ -185,6 +185,14 @@ int unetrir_bn_act_add_f32(const float* x, int ldx, long long P, int C, const fl
 int unetrir_act_bwd_f32(const float* da, int ldda, const float* out, int ldo, long long P, int C, int act, float* g,
                         int ldg, unetrir_stream_t stream);
 int unetrir_add_f32(const float* a, const float* b, float* y, long long n, unetrir_stream_t stream);
+/* Backward of the whole junction out = act(BatchNormalization(x) + skip) in three launches (reduce, finalize, apply) instead
+ * of seven: with g = da * act'(out) (decided by the sign of the stored OUTPUT `out`), dgamma / dbeta and dx are the BatchNorm
+ * backward of g, and gskip = g (+ gskip_add; gskip_add may be gskip itself: in-place accumulation when `skip` has another
+ * consumer whose gradient is already there; gskip NULL: the other operand needs no gradient).  ws >= unetrir_bn_ws_bytes(P, C). */
+int unetrir_bn_bwd_junction_f32(const float* da, int ldda, const float* x, int ldx, const float* out, int ldo, long long P, int C,
+                                const float* affine, const float* saved, int act, float* dx, int lddx, float* gskip, int ldgs,
+                                const float* gskip_add, int ldga, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                unetrir_stream_t stream);
 
 /* ---- boundary layout: the model input is NCHW [B,2,H,W] (north_star); the first conv reads
  *      NHWC padded to 4 channels.  nchw -> [B,H,W,Cpad] with zero fill, and back. */
@@ -356,6 +364,16 @@ int unetrir_conv2d_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf
 int unetrir_conv2d_dgrad_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
                                       const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, float* colstat,
                                       unetrir_stream_t stream);
+/* The same for every other convolution of the graphs (1x1 layers, strided layers, the tap-table path of small images): the
+ * implicit-GEMM kernel emits one row per 128-pixel tile of its launch.  unetrir_conv2d_colstat_rows_bf16 answers for these
+ * layers too (0 only where the serving kernel has none: 3x3 stride-2 forward, strided data gradients).  Conv2DTranspose
+ * forward (dl_models/res_ae.py:310-371: every decoder convolution of the residual graph sits in front of a BatchNormalization):
+ * stride 1 = one row per 128-pixel tile; stride 2 (1x1 'valid', 6x6) = the four output-parity classes, each with its own row
+ * range (4 x tiles rows); 3x3 stride 2: none (0). */
+long long unetrir_conv2d_transpose_colstat_rows_bf16(const unetrir_conv_geom* g, int ld_in);
+int unetrir_conv2d_transpose_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* wt,
+                                              const float* bias, unetrir_bf16* y, int ldy, float* colstat,
+                                              unetrir_stream_t stream);
 /* as unetrir_bn_stats_f32 / unetrir_colsum_f32 but from colstat rows; fixed-order fp64 reduction over the rows.
  * colsum: out[0..C) = sum over rows of colstat[row][c0 + c][0], ldc = channels per row. */
 int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, int C, const float* gamma, const float* beta,
@@ -390,6 +408,10 @@ int unetrir_bn_act_add_bf16(const unetrir_bf16* x, int ldx, long long P, int C, 
                             const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy, unetrir_stream_t stream);
 int unetrir_act_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* out, int ldo, long long P, int C, int act,
                          unetrir_bf16* g, int ldg, unetrir_stream_t stream);
+int unetrir_bn_bwd_junction_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x, int ldx, const unetrir_bf16* out, int ldo,
+                                 long long P, int C, const float* affine, const float* saved, int act, unetrir_bf16* dx, int lddx,
+                                 unetrir_bf16* gskip, int ldgs, const unetrir_bf16* gskip_add, int ldga, float* dgamma, float* dbeta,
+                                 void* ws, size_t ws_bytes, unetrir_stream_t stream);
 
 /* ---- waveform <-> feature transforms at the two ends of the data path; all fp32 in HBM,
  *      fp64 direct DFT inside.  n_fft is a power of two <= 1024, win_length <= n_fft, window = periodic Hann centred in

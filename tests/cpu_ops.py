@@ -92,6 +92,9 @@ class CpuOps:
     def conv2d_colstat_rows(self, g, dgrad, x):
         return 0
 
+    def conv2d_transpose_colstat_rows(self, g, x):
+        return 0
+
     def conv2d_wgrad_ws_bytes(self, g):
         return 1 << 12
 
@@ -194,6 +197,20 @@ class CpuOps:
         db, dg = gr.sum(0), (gr * xhat).sum(0)
         dgamma.copy_(dg.float()); dbeta.copy_(db.float())
         _put2(dx, scale * (gr - db / P - xhat * dg / P))
+
+    def bn_bwd_junction(self, da, x, out, affine, saved, dx, dgamma, dbeta, ws, act=2, gskip=None, gskip_add=None):
+        self.rt.touch([da, x, out, affine, saved, gskip_add], [dx, dgamma, dbeta, ws, gskip], "bn_bwd_junction")
+        C_ = x.C
+        v, P = _flat2(x), x.P
+        scale = affine[:C_].to(D)
+        mean, rstd = saved[:C_].to(D), saved[C_:].to(D)
+        xhat = (v - mean) * rstd
+        gr = _flat2(da) * _dact(_flat2(out), int(act))
+        db, dg = gr.sum(0), (gr * xhat).sum(0)
+        dgamma.copy_(dg.float()); dbeta.copy_(db.float())
+        _put2(dx, scale * (gr - db / P - xhat * dg / P))
+        if gskip is not None:
+            _put2(gskip, gr + (_flat2(gskip_add) if gskip_add is not None else 0.0))
 
     def colsum(self, x, out, ws):
         self.rt.touch([x], [out, ws], "colsum")

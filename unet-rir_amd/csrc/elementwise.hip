@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
                                                            const float* __restrict__ affine,
                                                            const float* __restrict__ saved, int relu,
                                                            long long P, int C, int QB, long long rows_per_slab,
-                                                           double* __restrict__ part) {
+                                                           double* __restrict__ part,
+                                                           const T* __restrict__ msk = nullptr, int ldm = 0) {
+    // msk (MODE 2, nullable): the activation's OUTPUT where it is not act(x*scale + shift) alone - the Add -> LeakyReLU junction
+    // of the residual blocks (dl_models/res_ae.py:334-336): ReLU / LeakyReLU keep the sign, so out > 0 decides the branch.
     constexpr int V = VecOf<T>::N;
     __shared__ double red[256 * 4];
     const int tid = threadIdx.x;
@@ -123,11 +126,12 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 #pragma unroll
                 for (int k = 0; k < V; ++k) s0[k] += (double)xv[k];
             } else {
-                float gv[V];
+                float gv[V], mv[V];
                 ldv(da + (size_t)p * ldda + c0, gv);
+                if (msk) ldv(msk + (size_t)p * ldm + c0, mv);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    const float a = xv[k] * sc[k] + sh[k];
+                    const float a = msk ? mv[k] : xv[k] * sc[k] + sh[k];
                     const float g = (relu && !(a > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
                     const float xh = (xv[k] - mu[k]) * rs[k];
                     s0[k] += (double)g; s1[k] += (double)g * (double)xh;
@@ -306,13 +310,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ affine,
                                                            const float* __restrict__ saved,
                                                            const float* __restrict__ coef, int relu,
-                                                           T* __restrict__ dx, int lddx) {
+                                                           T* __restrict__ dx, int lddx,
+                                                           const T* __restrict__ msk = nullptr, int ldm = 0,
+                                                           T* __restrict__ g2 = nullptr, int ldg2 = 0,
+                                                           const T* __restrict__ g2add = nullptr, int ldg2a = 0) {
     constexpr int V = VecOf<T>::N;
     const int CQ = C / V;
     const long long total = P * CQ;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nohoist = relu & 256; relu &= 255;
+    if (msk) {
+        // the Add -> activation junction (dl_models/res_ae.py:334-336, :478-480): g = da * act'(out) feeds BOTH branches - the
+        // BatchNorm backward of this one (dx) and the other operand of the Add (g2 = g (+ g2add): its gradient, written or
+        // accumulated in place here instead of by two more passes)
+        const int c0 = (int)(i0 % CQ) * V;
+        const bool hoist = stride % CQ == 0;
+        float sc[V], mu[V], rs[V], c1[V], c2[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) { sc[k] = affine[c0 + k]; mu[k] = saved[c0 + k]; rs[k] = saved[C + c0 + k]; c1[k] = coef[c0 + k]; c2[k] = coef[C + c0 + k]; }
+        for (long long i = i0; i < total; i += stride) {
+            const long long p = i / CQ;
+            const int cc = hoist ? c0 : (int)(i - p * CQ) * V;
+            if (!hoist) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) { sc[k] = affine[cc + k]; mu[k] = saved[cc + k]; rs[k] = saved[C + cc + k]; c1[k] = coef[cc + k]; c2[k] = coef[C + cc + k]; }
+            }
+            float xv[V], gv[V], mv[V], out[V], go[V];
+            ldv(x + (size_t)p * ldx + cc, xv);
+            ldv(da + (size_t)p * ldda + cc, gv);
+            ldv(msk + (size_t)p * ldm + cc, mv);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float g = (relu && !(mv[k] > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
+                const float xh = (xv[k] - mu[k]) * rs[k];
+                out[k] = sc[k] * (g - c1[k] - xh * c2[k]);
+                go[k] = g;
+            }
+            stv(dx + (size_t)p * lddx + cc, out);
+            if (g2) {
+                if (g2add) {
+                    float ad[V];
+                    ldv(g2add + (size_t)p * ldg2a + cc, ad);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) go[k] += ad[k];
+                }
+                stv(g2 + (size_t)p * ldg2 + cc, go);
+            }
+        }
+        return;
+    }
     if (affine && stride % CQ == 0 && !nohoist) {
         const int c0 = (int)(i0 % CQ) * V;
         float sc[V], sh[V], mu[V], rs[V], c1[V], c2[V];
@@ -657,6 +704,27 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     return (int)hipGetLastError();
 }
 
+// BatchNormalization -> Add -> activation junction, backward in three launches: reduce, finalize, apply (+ the Add's other operand)
+template <typename T>
+int bn_bwd_junction_impl(const T* da, int ldda, const T* x, int ldx, const T* out, int ldo, long long P, int C, const float* affine,
+                         const float* saved, int act, T* dx, int lddx, T* gskip, int ldgs, const T* gskip_add, int ldga,
+                         float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t s) {
+    constexpr int V = VecOf<T>::N;
+    if (!chan_ok(x, ldx, P, C, V) || !chan_ok(da, ldda, P, C, V) || !chan_ok(out, ldo, P, C, V) || !dx || lddx < C || lddx % V || !affine ||
+        !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C) || act < 0 || act > 2 || (gskip && (ldgs < C || ldgs % V)) ||
+        (gskip_add && (!gskip || ldga < C || ldga % V)))
+        return UNETRIR_EINVAL;
+    const ChanPlan pl = chan_plan(P, C, V);
+    double* part = (double*)ws;
+    float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
+    hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, da, ldda, affine, saved,
+                       act, P, C, pl.QB, pl.rows_per_slab, part, out, ldo);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
+                       (const float*)coef, act, dx, lddx, out, ldo, gskip, ldgs, gskip_add, ldga);
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
@@ -717,6 +785,14 @@ int unetrir_bn_bwd_f32(const float* da, int ldda, const float* x, int ldx, long 
                        float* dbeta, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
     (void)gamma;
     return bn_bwd_impl<float>(da, ldda, x, ldx, P, C, affine, saved, relu, dx, lddx, dgamma, dbeta, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_bn_bwd_junction_f32(const float* da, int ldda, const float* x, int ldx, const float* out, int ldo, long long P, int C,
+                                const float* affine, const float* saved, int act, float* dx, int lddx, float* gskip, int ldgs,
+                                const float* gskip_add, int ldga, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                unetrir_stream_t stream) {
+    return bn_bwd_junction_impl<float>(da, ldda, x, ldx, out, ldo, P, C, affine, saved, act, dx, lddx, gskip, ldgs, gskip_add, ldga,
+                                       dgamma, dbeta, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int unetrir_colsum_f32(const float* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes,
@@ -924,6 +1000,15 @@ int unetrir_bn_bwd_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x,
                         size_t ws_bytes, unetrir_stream_t stream) {
     return bn_bwd_impl<__bf16>((const __bf16*)da, ldda, (const __bf16*)x, ldx, P, C, affine, saved, relu, (__bf16*)dx, lddx, dgamma,
                                dbeta, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int unetrir_bn_bwd_junction_bf16(const unetrir_bf16* da, int ldda, const unetrir_bf16* x, int ldx, const unetrir_bf16* out, int ldo,
+                                 long long P, int C, const float* affine, const float* saved, int act, unetrir_bf16* dx, int lddx,
+                                 unetrir_bf16* gskip, int ldgs, const unetrir_bf16* gskip_add, int ldga, float* dgamma, float* dbeta,
+                                 void* ws, size_t ws_bytes, unetrir_stream_t stream) {
+    return bn_bwd_junction_impl<__bf16>((const __bf16*)da, ldda, (const __bf16*)x, ldx, (const __bf16*)out, ldo, P, C, affine, saved, act,
+                                        (__bf16*)dx, lddx, (__bf16*)gskip, ldgs, (const __bf16*)gskip_add, ldga, dgamma, dbeta, ws, ws_bytes,
+                                        (hipStream_t)stream);
 }
 
 int unetrir_colsum_bf16(const unetrir_bf16* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes,

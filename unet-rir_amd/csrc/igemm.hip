@@ -463,7 +463,16 @@ __global__ void splitk_rows_reduce_kernel(const float* __restrict__ part, int ns
     const long long p = i / N;
     const int n = (int)(i - p * N);
     float s = bias ? bias[n] : 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * M * N + i];
+    const size_t mn = (size_t)M * N;
+    int k = 0;
+    for (; k + 7 < nsplit; k += 8) {             // 8 independent loads in flight, added in slab order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * mn + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nsplit; ++k) s += part[(size_t)k * mn + i];
     y[p * ldy + n] = s;
 }
 
@@ -473,8 +482,19 @@ int launch_splitk_rows_reduce(const float* part, int nsplit, long long M, int N,
     return (int)hipGetLastError();
 }
 
-#define DENSE_KSPLIT 16
-size_t dense_fwd_ws_bytes(int B, int K, int N) { (void)K; return (size_t)DENSE_KSPLIT * B * N * sizeof(float); }
+// K slices of the small-batch Dense kernel: with only B <= 128 rows there are ceil(N / 128) (N <= 64: one) output tiles, so K is
+// split until ~512 workgroups stream the weight matrix; a slice keeps at least 256 k-values.  (16 for the U-Net's 8192 -> 4096
+// layer as before; the residual auto-encoder's 66 560 -> 32 latent layer had ONE tile and ran on 16 workgroups: 184 us.)
+static int dense_ksplit(int K, int N) {
+    const int tiles = N > 64 ? (N + 127) / 128 : 1;
+    int ks = (512 + tiles - 1) / tiles;
+    const int maxk = K / 256 > 0 ? K / 256 : 1;
+    if (ks > maxk) ks = maxk;
+    if (ks > 128) ks = 128;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+size_t dense_fwd_ws_bytes(int B, int K, int N) { return (size_t)dense_ksplit(K, N) * B * N * sizeof(float); }
 
 // Dense(N) on a small batch: y[B][N] = x[B][K] . w[N][K]^T + bias.  The weight matrix is streamed once; with only B rows
 // there are N/128 output tiles, so the K dimension is split 16 ways to put >= 2 workgroups on every CU.
@@ -486,12 +506,17 @@ int launch_dense_fwd(const float* x, int ldx, const float* w, const float* bias,
     a.g.OH = 1; a.g.OW = 1; a.g.N = N; a.g.ldo = ldy; a.g.SI = 1; a.g.SO = 1;
     a.g.ntaps = 1; a.g.wtaps = 1; a.g.tap[0] = 0;
     a.in = x; a.w = w; a.out = y;
-    a.ksplit = DENSE_KSPLIT; a.part = (float*)ws;
+    const int ks = dense_ksplit(K, N);
+    if (ks == 1) {            // enough output tiles on their own: the kernel's ordinary epilogue writes y (+ bias)
+        a.bias = bias; a.ksplit = 0; a.part = nullptr;
+        return launch_igemm_fwd(a, s);
+    }
+    a.ksplit = ks; a.part = (float*)ws;
     int err = launch_igemm_fwd(a, s);
     if (err) return err;
     const long long tot = (long long)B * N;
     hipLaunchKernelGGL(splitk_rows_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float*)ws,
-                       DENSE_KSPLIT, (long long)B, N, bias, y, ldy);
+                       ks, (long long)B, N, bias, y, ldy);
     return (int)hipGetLastError();
 }
 
@@ -533,8 +558,52 @@ int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* 
     return err;
 }
 
+// Few outputs, many slabs (the 1x1 and small 3x3 weight gradients of the residual graphs: 1 K .. 64 K floats from up to 512
+// slabs): the kernel above would run a handful of workgroups that each walk 64 slabs one after the other.  Here a workgroup
+// owns 16 float4 columns and 32 slab groups: group g sums slabs g, g + 32, ... (8 loads in flight), the 32 group sums are added
+// in a fixed order.  16 lanes x 16 bytes = one 256-byte piece of a slab per group and step.
+__global__ __launch_bounds__(512) void splitk_reduce_wide_kernel(const float* __restrict__ part, int nsplit, size_t n,
+                                                                 float* __restrict__ out, float reg, const float* __restrict__ w) {
+    __shared__ float4 red[32][16];
+    const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i4 = ((size_t)blockIdx.x * 16 + lane) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n) {                                   // n % 4 == 0 (checked by the launcher)
+        const float* p = part + i4;
+        int k = grp;
+        for (; k + 7 * 32 < nsplit; k += 8 * 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + u * 32) * n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; k < nsplit; k += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0 || i4 >= n) return;
+#pragma unroll
+    for (int g = 1; g < 32; ++g) {
+        const float4 v = red[g][lane];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (reg != 0.f) {
+        const float4 v = *reinterpret_cast<const float4*>(w + i4);
+        s.x += reg * v.x; s.y += reg * v.y; s.z += reg * v.z; s.w += reg * v.w;
+    }
+    *reinterpret_cast<float4*>(out + i4) = s;
+}
+
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s) {
     const size_t n4 = (n + 3) / 4;
+    if ((n & 3) == 0 && nsplit >= 32 && (n4 + 63) / 64 < 128 && (((uintptr_t)part | (uintptr_t)out | (uintptr_t)w) & 15) == 0) {
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(512), 0, s, part, nsplit, n, out, reg, w);
+        return (int)hipGetLastError();
+    }
     const dim3 grid((unsigned)((n4 + 63) / 64));
     if (nsplit >= 8) hipLaunchKernelGGL(splitk_reduce_kernel<8>, grid, dim3(512), 0, s, part, nsplit, n, out, reg, w);
     else if (nsplit >= 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, grid, dim3(256), 0, s, part, nsplit, n, out, reg, w);

@@ -203,7 +203,10 @@ __device__ __forceinline__ void igemm_fwd_bf16_body(const IgemmArgsH& a, const i
             const int rem = (int)(p - (long long)nimg * plane);
             const int py = rem / a.g.PW, px = rem - py * a.g.PW;
             const int oy = py * a.g.SO + a.g.ooy, ox = px * a.g.SO + a.g.oox;
-            if (oy >= a.g.OH || ox >= a.g.OW) continue;
+            if (oy >= a.g.OH || ox >= a.g.OW) {           // not stored: not part of the column statistics either
+                if (a.colstat != nullptr) *reinterpret_cast<uint4*>(stage + prow * SROW + cq * 8) = make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
             opix = ((long long)nimg * a.g.OH + oy) * a.g.OW + ox;
         }
         bf16x8 v = *reinterpret_cast<const bf16x8*>(stage + prow * SROW + cq * 8);
@@ -212,6 +215,7 @@ __device__ __forceinline__ void igemm_fwd_bf16_body(const IgemmArgsH& a, const i
                 const bf16x8 ad = *reinterpret_cast<const bf16x8*>(a.addend + opix * a.ldadd + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)ad[e]);
+                if (a.colstat != nullptr) *reinterpret_cast<bf16x8*>(stage + prow * SROW + cq * 8) = v;     // statistics of what is stored
             }
             *reinterpret_cast<bf16x8*>(a.out + opix * a.g.ldo + n) = v;
         } else {          // ragged channel tail (N not a multiple of 8 never happens for activations; kept for safety)
@@ -219,6 +223,33 @@ __device__ __forceinline__ void igemm_fwd_bf16_body(const IgemmArgsH& a, const i
                 float f = (float)v[e];
                 if (a.addend != nullptr) f += (float)a.addend[opix * a.ldadd + n + e];
                 a.out[opix * a.g.ldo + n + e] = (__bf16)f;
+            }
+        }
+    }
+    if (a.colstat != nullptr) {
+        __syncthreads();          // the store loop may have put addend sums back into the staging tiles
+        // fused column statistics (BatchNormalization batch statistics without re-reading the tensor): per-channel (sum, sum of
+        // squares) of the bf16 values this 128-pixel tile is about to store, in a fixed order: each wave sums the 64 pixel rows of
+        // its staging tile (WN = 32: two lanes per channel, 32 rows each, combined by one cross-lane add), the two waves that
+        // share a channel range are added through LDS.
+        __shared__ float s_cs[4][64][2];
+        constexpr int LPC = 64 / WN, RPL = 64 / LPC;
+        const int ch = lane % WN, half = lane / WN;
+        float cs = 0.f, css = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < RPL; ++r) {
+            const int prow = half * RPL + r;
+            if (m0 + wm * 64 + prow < M) { const float v = (float)stage[prow * SROW + ch]; cs += v; css += v * v; }
+        }
+        if (LPC == 2) { cs += __shfl_xor(cs, 32); css += __shfl_xor(css, 32); }
+        if (lane < WN) { s_cs[wave][ch][0] = cs; s_cs[wave][ch][1] = css; }
+        __syncthreads();
+        if (tid < BN_) {
+            const int wn_ = tid / WN, c = tid % WN, nn = n0 + wn_ * WN + c;
+            if (nn < a.g.N) {
+                float* row = a.colstat + ((size_t)mt * a.g.N + nn) * 2;
+                row[0] = s_cs[wn_][c][0] + s_cs[2 + wn_][c][0];
+                row[1] = s_cs[wn_][c][1] + s_cs[2 + wn_][c][1];
             }
         }
     }

@@ -83,7 +83,11 @@ struct IgemmArgsH {
     const __bf16* addend;  // nullable
     int ldadd;
     __bf16* out;
+    float* colstat;        // nullable: [pixel tile][N][2] per-channel (sum, sum of squares) of the stored bf16 output, one row per
+                           // 128-pixel tile of the launch (row = tile index); requires addend == nullptr
 };
+// rows of column statistics one tap-table launch writes (= its 128-pixel tiles)
+inline long long igemm_colstat_rows(long long tile_pixels) { return (tile_pixels + 127) / 128; }
 struct Wgrad3ArgsH {
     const __bf16* x; int ldx; int IH, IW;
     const __bf16* dy; int lddy; int OH, OW;
@@ -146,6 +150,13 @@ int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
 // One slot per stream (launches on a stream run in order; the last workgroup of a launch clears the slot); nullptr when more
 // than 128 streams are in use - the kernels then keep their fixed assignment.
 unsigned* sched_slot(hipStream_t s);
+// Arrival counters for kernels whose LAST workgroup (of the launch, or of one output tile) finishes a reduction the others fed
+// (gridsync.h): UNETRIR_SYNC_WORDS zero-initialised words per (device, stream); words [0, UNETRIR_SYNC_TILES) count arrivals per
+// output tile, word UNETRIR_SYNC_TILES counts arrivals of a whole launch.  nullptr when no slot is available (more than 128
+// streams in use, or first use inside a stream capture): the launchers then run the separate reduction kernel.
+#define UNETRIR_SYNC_TILES 512
+#define UNETRIR_SYNC_WORDS 520
+unsigned* sync_slot(hipStream_t s);
 bool conv3x3p_applies(const Conv3Args& a);          // conv3x3g's layers with >= 512 tiles: persistent form, continuous K loop across tiles
 long long conv3x3p_colstat_rows(const Conv3Args& a);
 int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s);

@@ -25,7 +25,7 @@ RELU, LEAKY = 1, 2       # activation codes of the C ABI (LeakyReLU: keras defau
 
 class Node:
     """An activation buffer (or a channel slice of one) and the buffer of its gradient."""
-    __slots__ = ("a", "g", "g_set", "needs_grad", "children")
+    __slots__ = ("a", "g", "g_set", "needs_grad", "children", "cst")
 
     def __init__(self, a: Act, needs_grad=True, g: Act = None):
         self.a = a
@@ -33,6 +33,7 @@ class Node:
         self.g_set = False
         self.needs_grad = needs_grad
         self.children = []           # channel-slice views: written whenever this node's gradient is written
+        self.cst = None              # (rows, buffer): fused column statistics the producing convolution wrote (BatchNorm statistics)
 
 
 class GraphEngine(DeviceCounters):
@@ -51,6 +52,8 @@ class GraphEngine(DeviceCounters):
             raise ValueError("dtype must be 'f32' or 'bf16'")
         self.dtype = dtype
         self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
+        self.fused_junction = True                     # BatchNorm -> Add -> activation backward in one reduce / finalize / apply sequence
+        self.fused_stats = True                        # BatchNorm statistics from the convolution epilogues where the kernel has them (bf16)
         self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes (zero-padded 2-channel ends)
         self._h_kernels = []                           # kernels of the convolutions that run in bf16 (work copies needed)
         self._s2_kernels = []                          # 3x3 stride-2 kernels among them
@@ -187,6 +190,11 @@ class GraphEngine(DeviceCounters):
         wpk = lambda: self._ppk.get(kname)
         wf = (lambda: self._ph[kname]) if h16 else (lambda: self._p[kname])       # kernel as stored ([N][T][C])
         wb = (lambda: self._pth[kname]) if h16 else (lambda: self._pt[kname])     # channel roles swapped ([C][T][N])
+        # BatchNormalization statistics from the convolution's own epilogue (bf16 trunk): the tensor is not read again for them
+        rows = 0
+        if h16 and followed_by_bn and self.fused_stats and not dense and out is None:
+            rows = ops.conv2d_transpose_colstat_rows(g, x.a) if transpose else ops.conv2d_colstat_rows(g, 0, x.a)
+        cst = torch.empty((rows, co, 2), dtype=torch.float32, device=self.device) if rows else None
 
         def dense_dgrad(dst, add):
             if add is None:      # split-K path: the weight matrix streams from every CU
@@ -195,8 +203,15 @@ class GraphEngine(DeviceCounters):
                 ops.conv2d_dgrad(g, y.g, self._pt[kname], dst, addend=add)
 
         def fwd():
+            y.cst = None
             if dense:
                 ops.dense_fwd(x.a, self._p[kname], self._p[bname], y.a, self.ws)
+            elif cst is not None and self.training:
+                if transpose:
+                    ops.conv2d_transpose_fwd_colstat(g, x.a, wb(), self._p[bname], y.a, cst)
+                else:
+                    ops.conv2d_fwd_colstat(g, x.a, wf(), self._p[bname], y.a, cst)
+                y.cst = (rows, cst)
             elif transpose:
                 ops.conv2d_transpose_fwd(g, x.a, wb(), self._p[bname], y.a)
             else:
@@ -270,10 +285,13 @@ class GraphEngine(DeviceCounters):
                 mm = torch.zeros(c, dtype=torch.float32, device=self.device)
                 mv = torch.ones(c, dtype=torch.float32, device=self.device)
             self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"] = mm, mv
-        gj = Act(torch.empty_like(x.a.base)) if addend is not None else None
+        gj = Act(torch.empty_like(x.a.base)) if (addend is not None and not (batchnorm and self.fused_junction)) else None
 
         def fwd():
-            if batchnorm and self.training:
+            if batchnorm and self.training and x.cst is not None:
+                ops.bn_stats_colstat(x.cst[1], x.cst[0], x.a.P, c, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, mm, mv,
+                                     BN_EPS, BN_MOMENTUM)
+            elif batchnorm and self.training:
                 ops.bn_stats(x.a, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, self.ws, mm, mv, BN_EPS, BN_MOMENTUM)
             elif batchnorm:          # training=False: normalise with the moving statistics
                 ops.bn_inference_affine(self._p[name + ".gamma"], self._p[name + ".beta"], mm, mv, BN_EPS, aff)
@@ -284,7 +302,17 @@ class GraphEngine(DeviceCounters):
                 ops.bn_bwd(y.g, x.a, None, aff, saved, x.g, self._g[name + ".gamma"], self._g[name + ".beta"], self.ws, relu=act)
             elif addend is None:
                 ops.act_bwd(y.g, y.a, x.g, act)
-            else:      # junction y = act(bn(x) + addend): g = dy * act'(y) feeds both branches
+            elif batchnorm and self.fused_junction:
+                # junction y = act(bn(x) + addend): g = dy * act'(y) feeds both branches; one reduce / finalize / apply sequence
+                # writes dx, dgamma, dbeta AND the addend's gradient (written, or accumulated in place behind an earlier writer)
+                def junction(dst, add):
+                    ops.bn_bwd_junction(y.g, x.a, y.a, aff, saved, x.g, self._g[name + ".gamma"], self._g[name + ".beta"], self.ws, act,
+                                        gskip=dst, gskip_add=add)
+                if addend.needs_grad:
+                    self._emit(addend, junction)
+                else:
+                    junction(None, None)
+            else:      # the same in separate passes
                 if act:
                     ops.act_bwd(y.g, y.a, gj, act)
                     gsrc = gj

@@ -140,6 +140,19 @@ def conv2d_dgrad_colstat(g, dy: Act, wt, dx: Act, colstat, addend: Act = None):
           "conv2d_dgrad_colstat")
 
 
+def conv2d_transpose_colstat_rows(g, x: Act):
+    """Rows of fused column statistics of a Conv2DTranspose forward launch (0: none; bf16 storage only)."""
+    if x.sfx != "bf16":
+        return 0
+    return int(_lib.lib().unetrir_conv2d_transpose_colstat_rows_bf16(C.byref(g), x.ld))
+
+
+def conv2d_transpose_fwd_colstat(g, x: Act, wt, bias, y: Act, colstat):
+    """conv2d_transpose_fwd that also writes per-tile (sum, sum of squares) of the stored output: colstat [rows][Cout][2] fp32."""
+    check(_lib.lib().unetrir_conv2d_transpose_fwd_colstat_bf16(C.byref(g), _p(x), x.ld, _p(wt), _p(bias), _p(y), y.ld, _p(colstat),
+                                                               _stream()), "conv2d_transpose_fwd_colstat")
+
+
 def bn_stats_colstat(colstat, rows, P, C_, gamma, beta, affine, saved, moving_mean=None, moving_var=None, eps=1e-3, momentum=0.99):
     """BatchNormalization() batch statistics from fused conv-epilogue partials."""
     check(_lib.lib().unetrir_bn_stats_colstat(_p(colstat), rows, P, C_, _p(gamma), _p(beta), eps, momentum, _p(moving_mean),
@@ -311,6 +324,17 @@ def bn_act_add(x: Act, affine, y: Act, act=2, addend: Act = None):
     """BatchNormalization -> Add -> activation (dl_models/res_ae.py:331-336); act 0 none, 1 ReLU, 2 LeakyReLU(0.3)."""
     check(_fn("bn_act_add", x.sfx)(_p(x), x.ld, x.P, x.C, _p(affine), int(act), _p(addend),
                                    addend.ld if addend is not None else 0, _p(y), y.ld, _stream()), "bn_act_add")
+
+
+def bn_bwd_junction(da: Act, x: Act, out: Act, affine, saved, dx: Act, dgamma, dbeta, ws: Workspace, act=2, gskip: Act = None,
+                    gskip_add: Act = None):
+    """Backward of out = act(BatchNormalization(x) + skip) (dl_models/res_ae.py:334-336, :478-480): dx, dgamma, dbeta and the
+    gradient of `skip` (gskip = g (+ gskip_add)) from one reduce / finalize / apply sequence."""
+    ws.reserve(bn_ws_bytes(x.P, x.C))
+    check(_fn("bn_bwd_junction", x.sfx)(_p(da), da.ld, _p(x), x.ld, _p(out), out.ld, x.P, x.C, _p(affine), _p(saved), int(act), _p(dx), dx.ld,
+                                        _p(gskip), gskip.ld if gskip is not None else 0, _p(gskip_add),
+                                        gskip_add.ld if gskip_add is not None else 0, _p(dgamma), _p(dbeta), ws.ptr, ws.nbytes, _stream()),
+          "bn_bwd_junction")
 
 
 def act_bwd(da: Act, out: Act, g: Act, act=2):
