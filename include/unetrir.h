@@ -62,10 +62,10 @@ int unetrir_abi_version(void);
  *      this struct; unetrir_set_config replaces the values in effect (tests, A/B scripts: process-global, not
  *      thread-safe - call it while no launch is being issued).  Defaults: all 1.
  *        conv3x3        UNETRIR_CONV3X3        3x3 stride-1: patch-staged kernels at all (0: tap-table implicit GEMM)
- *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels (conv3x3g.hip)
+ *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels, and 64 output channels from > 64 input channels (64-channel tiles; conv3x3g.hip)
  *        conv3x3g_pair  UNETRIR_CONV3X3G_PAIR  its two-images-per-tile form for images <= 16 wide: 0 off, 1 when it yields
  *                                              >= 128 workgroups, 2 whenever the shape allows
- *        conv3x3h       UNETRIR_CONV3X3H       bf16 LDS-DMA kernel, <= 64 output channels (conv3x3h.hip)
+ *        conv3x3h       UNETRIR_CONV3X3H       bf16 LDS-DMA kernel, <= 64 output channels where conv3x3g / conv3x3s do not take the layer (conv3x3h.hip)
  *        conv3x3s       UNETRIR_CONV3X3S       bf16 strip kernel, 64 -> 64 channels, kernel resident in LDS (conv3x3s.hip)
  *        conv3x3r       UNETRIR_CONV3X3R       bf16 register-staged row-reuse kernel (conv3x3r.hip)
  *        stem           UNETRIR_STEM           bf16 first layer, 8 stored input channels (stem3x3.hip)
@@ -77,10 +77,11 @@ int unetrir_abi_version(void);
  *        conv3x3d       UNETRIR_CONV3X3D       bf16 LDS-DMA 3x3 stride-2 forward / transposed data gradient (conv3x3d.hip)
  *        conv3x3p       UNETRIR_CONV3X3P       bf16 persistent form of conv3x3g for layers with >= 512 tiles (conv3x3p.hip)
  *        upconv3x3q     UNETRIR_UPCONV3X3Q     bf16 persistent form of upconv3x3g for layers with >= 512 tiles (upconv3x3q.hip)
- *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup) */
+ *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup)
+ *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles;
+        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);

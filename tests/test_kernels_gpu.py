@@ -781,3 +781,85 @@ def test_stem_conv_bf16(U, case):
     again = ops.Act(torch.zeros((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
     ops.conv2d_fwd(g, xa, wh, b.float().to(DEV), again)
     assert torch.equal(again.base, ya.base[..., :Co])
+
+
+@pytest.mark.parametrize("case", [(3, 9, 10, 32, 64), (2, 16, 24, 64, 32), (5, 7, 12, 128, 128), (2, 8, 8, 256, 256), (4, 12, 20, 8, 32),
+                                  (2, 33, 17, 16, 96)])
+def test_pw1x1_kernel_against_the_tap_table_kernel_and_the_oracle(U, case):
+    """The register-streaming 1x1 kernel (pw1x1.hip) in every form the residual graphs launch it (dl_models/res_ae.py:310-371,
+    :453-514): Conv2D forward at stride 1 and 2 (bias, fused column statistics, addend), its data gradients (stride 2: scatter to
+    the even pixels, zeros - or the untouched in-place addend - elsewhere, odd sizes included), Conv2DTranspose forward at
+    stride 1 and at stride 2 'valid' (bias in the three other pixels of every cell) and its data gradient.  Same arithmetic as the
+    tap-table kernel (one fp32 MFMA chain over C, one rounding): identical bits; plus the oracle on the forward results."""
+    ops = U.ops
+    B, H, W, Ci, Co = case
+    gen = torch.Generator(device=DEV); gen.manual_seed(B * 100 + Ci)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    old = ops.get_config()
+    out = {}
+    try:
+        for on in (1, 0):
+            ops.set_config(pw1x1=on)
+            gen.manual_seed(B * 100 + Ci)
+            res = []
+            for s in (1, 2):
+                g = ops.geom(B, H, W, Ci, Co, 1, s)
+                Ho, Wo = -(-H // s), -(-W // s)
+                x = ops.Act(rnd(B, H, W, Ci + 8), 0, Ci)
+                if Ci == 8:
+                    x.base[..., 2:8] = 0
+                w, wt = (rnd(Co, 1, Ci).float() * 0.2).to(torch.bfloat16), (rnd(Ci, 1, Co).float() * 0.2).to(torch.bfloat16)
+                bias = torch.rand(Co, device=DEV, generator=gen) - 0.5
+                add = ops.Act(rnd(B, Ho, Wo, Co))
+                # Conv2D forward: plain, with addend, with column statistics
+                y = ops.Act(torch.full((B, Ho, Wo, Co + 8), 3.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+                ops.conv2d_fwd(g, x, w, bias, y, addend=add)
+                rows = ops.conv2d_colstat_rows(g, 0, x)
+                assert rows > 0
+                y2 = ops.Act(torch.empty((B, Ho, Wo, Co), dtype=torch.bfloat16, device=DEV))
+                cst = torch.full((rows, Co, 2), 7.0, device=DEV)
+                ops.conv2d_fwd_colstat(g, x, w, bias, y2, cst)
+                # Conv2D data gradient: written, and accumulated in place behind an earlier writer
+                gy = ops.Act(rnd(B, Ho, Wo, Co))
+                dx = ops.Act(torch.full((B, H, W, Ci), 5.0, dtype=torch.bfloat16, device=DEV))
+                ops.conv2d_dgrad(g, gy, wt, dx)
+                acc0 = rnd(B, H, W, Ci)
+                dacc = ops.Act(acc0.clone())
+                ops.conv2d_dgrad(g, gy, wt, dacc, addend=dacc)
+                # Conv2DTranspose(Ci -> Co, 1x1, stride s) on the H x W grid: forward (+ statistics), data gradient
+                gt = ops.geom(B, H, W, Ci, Co, 1, s)
+                wtr, wprim = (rnd(Co, 1, Ci).float() * 0.2).to(torch.bfloat16), (rnd(Ci, 1, Co).float() * 0.2).to(torch.bfloat16)
+                yt = ops.Act(torch.empty((B, H * s, W * s, Co), dtype=torch.bfloat16, device=DEV))
+                rows_t = ops.conv2d_transpose_colstat_rows(gt, x)
+                assert rows_t > 0
+                cst_t = torch.full((rows_t, Co, 2), 7.0, device=DEV)
+                ops.conv2d_transpose_fwd_colstat(gt, x, wtr, bias, yt, cst_t)
+                gyt = ops.Act(rnd(B, H * s, W * s, Co))
+                dxt = ops.Act(torch.empty((B, H, W, Ci), dtype=torch.bfloat16, device=DEV))
+                ops.conv2d_transpose_dgrad(gt, gyt, wprim, dxt)
+                torch.cuda.synchronize()
+                res.append(dict(y=y.base.clone(), y2=y2.base.clone(), cs=cst.double().sum(0), dx=dx.base.clone(), dacc=dacc.base.clone(),
+                                acc0=acc0, yt=yt.base.clone(), cst=cst_t.double().sum(0), dxt=dxt.base.clone(), x=x, w=w, wtr=wtr,
+                                bias=bias, add=add.base.clone()))
+            out[on] = res
+    finally:
+        ops.set_config(**old)
+    for s_i, (a, b) in enumerate(zip(out[1], out[0])):
+        for k in ("y", "y2", "dx", "dacc", "yt", "dxt"):
+            assert torch.equal(a[k], b[k]), (k, s_i + 1, float((a[k].float() - b[k].float()).abs().max()))
+        assert float(a["y"][..., Co:].float().min()) == 3.0                       # the neighbouring channels of the buffer are untouched
+        for k, t in (("cs", a["y2"]), ("cst", a["yt"])):
+            td = t.double()
+            close(a[k][:, 0], td.sum(dim=(0, 1, 2)), 2e-6, f"{k} sum")
+            close(a[k][:, 1], (td * td).sum(dim=(0, 1, 2)), 2e-6, f"{k} sum of squares")
+        # oracle: forward (+ addend) and the transposed forward
+        s = s_i + 1
+        xo = a["x"].base[..., :Ci].double().cpu().permute(0, 3, 1, 2)
+        w_hwio = a["w"].double().cpu().view(Co, 1, 1, Ci).permute(1, 2, 3, 0)
+        want = R.conv2d_same(xo, w_hwio, a["bias"].double().cpu(), s) + a["add"].double().cpu().permute(0, 3, 1, 2)
+        got = a["y"][..., :Co].double().cpu().permute(0, 3, 1, 2)
+        assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
+        k_hwoi = a["wtr"].double().cpu().view(Co, 1, 1, Ci).permute(1, 2, 0, 3)     # [kh,kw,O,I]
+        want_t = R.conv2d_transpose_same(xo, k_hwoi, a["bias"].double().cpu(), s)
+        got_t = a["yt"].double().cpu().permute(0, 3, 1, 2)
+        assert float((got_t - want_t).abs().max()) <= 1e-2 * float(want_t.abs().max())

@@ -30,6 +30,7 @@ unetrir_config load_config() {
     c.upconv3x3q = env_int("UNETRIR_UPCONV3X3Q", 1);
     c.dyn_tiles = env_int("UNETRIR_DYN_TILES", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
+    c.pw1x1 = env_int("UNETRIR_PW1X1", 1);
     return c;
 }
 unetrir_config& config_storage() {
@@ -196,6 +197,32 @@ inline bool use_conv3x3(int k, int stride, int H, int W) {
     return util >= 0.7;
 }
 
+// 1x1 layers in bf16 storage: the register-streaming kernel (pw1x1.hip).  Forward form: gather at the convolution's stride;
+// data-gradient form (also Conv2DTranspose forward): scatter at the stride, the other pixels of a 2 x 2 cell filled with bias
+// (+ addend) - for k = 1 TF 'same' has no padding at either stride, so input pixel = stride * output pixel exactly.
+inline PwArgs pw_fwd_args(const unetrir_conv_geom* g, const void* x, int ldx, const void* w, const float* bias, const void* addend,
+                          int ldadd, void* y, int ldy, float* colstat) {
+    PwArgs a{};
+    const Same sy = same_geom(g->H, 1, g->stride), sx = same_geom(g->W, 1, g->stride);
+    a.in = (const __bf16*)x; a.ldi = ldx; a.IH = g->H; a.IW = g->W;
+    a.w = (const __bf16*)w; a.bias = bias; a.addend = (const __bf16*)addend; a.ldadd = ldadd;
+    a.out = (__bf16*)y; a.ldo = ldy; a.OH = sy.out; a.OW = sx.out;
+    a.B = g->B; a.PH = sy.out; a.PW = sx.out; a.SI = g->stride; a.SO = 1; a.fill = 0;
+    a.C = g->Cin; a.N = g->Cout; a.colstat = colstat;
+    return a;
+}
+inline PwArgs pw_dgrad_args(const unetrir_conv_geom* g, const void* dy, int lddy, const void* wt, const float* bias, const void* addend,
+                            int ldadd, void* dx, int lddx, float* colstat) {
+    PwArgs a{};
+    const Same sy = same_geom(g->H, 1, g->stride), sx = same_geom(g->W, 1, g->stride);
+    a.in = (const __bf16*)dy; a.ldi = lddy; a.IH = sy.out; a.IW = sx.out;
+    a.w = (const __bf16*)wt; a.bias = bias; a.addend = (const __bf16*)addend; a.ldadd = ldadd;
+    a.out = (__bf16*)dx; a.ldo = lddx; a.OH = g->H; a.OW = g->W;
+    a.B = g->B; a.PH = sy.out; a.PW = sx.out; a.SI = 1; a.SO = g->stride; a.fill = g->stride == 2 ? 1 : 0;
+    a.C = g->Cout; a.N = g->Cin; a.colstat = colstat;
+    return a;
+}
+
 struct F32 {
     static constexpr int is_bf16 = 0;
     using T = float; using Args = IgemmArgs;
@@ -237,6 +264,12 @@ int conv_fwd_impl(const unetrir_conv_geom* g, const typename P::T* x, int ldx, c
             if (conv3x3d_applies(c)) return launch_conv3x3d_bf16(c, s);
         }
     }
+    if constexpr (P::is_bf16) {
+        if (g->k == 1) {
+            const PwArgs pw = pw_fwd_args(g, x, ldx, w, bias, addend, ldadd, y, ldy, colstat);
+            if (pw1x1_applies(pw)) return launch_pw1x1_bf16(pw, s);
+        }
+    }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
     a.g.B = g->B; a.g.PH = sy.out; a.g.PW = sx.out;
@@ -263,6 +296,12 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
         c.in = dy; c.ldi = lddy; c.w = wt; c.bias = bias; c.addend = addend; c.ldadd = ldadd; c.out = dx; c.ldo = lddx;
         c.B = g->B; c.H = g->H; c.W = g->W; c.C = g->Cout; c.N = g->Cin; c.flip = 1;
         if (use_conv3x3(g->k, g->stride, g->H, g->W) || (P::is_bf16 && conv3x3g_pair_applies(c))) return launch_conv3x3(c, P::is_bf16, s);
+    }
+    if constexpr (P::is_bf16) {
+        if (g->k == 1) {
+            const PwArgs pw = pw_dgrad_args(g, dy, lddy, wt, bias, addend, ldadd, dx, lddx, colstat);
+            if (pw1x1_applies(pw)) return launch_pw1x1_bf16(pw, s);
+        }
     }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     typename P::Args a{};
@@ -494,6 +533,11 @@ static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) 
     // stride 1: the input grid).  Strided data gradients have no fused statistics through this entry point.
     const long long igemm_rows = dgrad ? (g->stride == 1 ? igemm_colstat_rows((long long)g->B * g->H * g->W) : 0)
                                        : igemm_colstat_rows((long long)g->B * sy.out * sx.out);
+    if (g->k == 1) {          // the register-streaming 1x1 kernel: one row per persistent workgroup
+        const PwArgs pw = dgrad ? pw_dgrad_args(g, nullptr, ld_in, nullptr, nullptr, nullptr, 0, nullptr, g->Cin, nullptr)
+                                : pw_fwd_args(g, nullptr, ld_in, nullptr, nullptr, nullptr, 0, nullptr, g->Cout, nullptr);
+        if (pw1x1_applies(pw)) return pw1x1_colstat_rows(pw);
+    }
     if (g->k != 3 || g->stride != 1) return (g->k == 3 && g->stride == 2 && !dgrad) ? 0 : igemm_rows;    // 3x3 stride 2 forward: conv3x3d (none)
     Conv3Args c{};
     c.B = g->B; c.H = g->H; c.W = g->W; c.ldi = ld_in;
@@ -517,6 +561,11 @@ static long long colstat_rows_transpose(const unetrir_conv_geom* g, int ld_in) {
         return colstat_rows(&c, 1, ld_in);
     }
     if (g->k == 3) return 0;
+    if (g->k == 1) {
+        const unetrir_conv_geom c = adjoint_geom(g);
+        const PwArgs pw = pw_dgrad_args(&c, nullptr, ld_in, nullptr, nullptr, nullptr, 0, nullptr, g->Cout, nullptr);
+        if (pw1x1_applies(pw)) return pw1x1_colstat_rows(pw);
+    }
     return 4 * igemm_colstat_rows((long long)g->B * g->H * g->W);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }

@@ -173,4 +173,21 @@ bool dense_dgrad_applies(int B, int K, int N);
 size_t dense_dgrad_ws_bytes(int B, int K, int N);
 int launch_dense_dgrad(const float* dy, int lddy, const float* w, float* dx, int lddx, int B, int K, int N, void* ws, size_t ws_bytes,
                        hipStream_t s);
-int launch_upconv3x3(const Conv3Args& a, int bf16, hipStream_t s);   // H, W = coarse (input) grid; output 2H x 2W
+int launch_upconv3x3(const Conv3Args& a, int bf16, hipStream_t s);
+
+// 1x1 convolutions (pw1x1.hip): out[opix(p)][n] = sum_c in[ipix(p)][c] w[n][c] + bias[n] (+ addend) over the iteration grid
+// B x PH x PW; ipix = (b, py SI, px SI) of the IH x IW input grid, opix = (b, py SO, px SO) of the OH x OW output grid; fill
+// (SO = 2): the three other pixels of each 2 x 2 output cell are written with bias (+ addend).
+struct PwArgs {
+    const __bf16* in; int ldi; int IH, IW;
+    const __bf16* w;                 // [N][C], C contiguous
+    const float* bias;               // nullable
+    const __bf16* addend; int ldadd; // nullable; indexed like out (may be out itself)
+    __bf16* out; int ldo; int OH, OW;
+    int B, PH, PW, SI, SO, fill;
+    int C, N;
+    float* colstat;                  // nullable: [pw1x1_colstat_rows][N][2]; requires addend == nullptr
+};
+bool pw1x1_applies(const PwArgs& a);
+long long pw1x1_colstat_rows(const PwArgs& a);
+int launch_pw1x1_bf16(const PwArgs& a, hipStream_t s);   // H, W = coarse (input) grid; output 2H x 2W
