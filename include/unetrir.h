@@ -64,7 +64,7 @@ int unetrir_abi_version(void);
  *        conv3x3        UNETRIR_CONV3X3        3x3 stride-1: patch-staged kernels at all (0: tap-table implicit GEMM)
  *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels, and 64 output channels from > 64 input channels (64-channel tiles; conv3x3g.hip)
  *        conv3x3g_pair  UNETRIR_CONV3X3G_PAIR  its two-images-per-tile form for images <= 16 wide: 0 off, 1 when it yields
- *                                              >= 128 workgroups, 2 whenever the shape allows
+ *                                              >= 32 workgroups (64-channel tiles), 2 whenever the shape allows
  *        conv3x3h       UNETRIR_CONV3X3H       bf16 LDS-DMA kernel, <= 64 output channels where conv3x3g / conv3x3s do not take the layer (conv3x3h.hip)
  *        conv3x3s       UNETRIR_CONV3X3S       bf16 strip kernel, 64 -> 64 channels, kernel resident in LDS (conv3x3s.hip)
  *        conv3x3r       UNETRIR_CONV3X3R       bf16 register-staged row-reuse kernel (conv3x3r.hip)
@@ -276,8 +276,9 @@ int unetrir_dropout_mask_dev_f32(float* mask, long long n, float p, unsigned lon
 /* ---- bf16-storage variants (BASELINE.json configs[1] names bf16): activations, their gradients and the weight work
  *      copies are bfloat16 (unetrir_bf16), accumulation is fp32 (v_mfma_f32_32x32x16_bf16), bias / BatchNorm parameters /
  *      statistics / weight gradients / master weights stay fp32.  Channel counts and pixel strides are multiples of 8
- *      (16-byte rows).  Same call sites as the _f32 entry points above.  The weight gradient exists for 3x3 kernels
- *      and 1x1 kernels (the Dense layers stay fp32). */
+ *      (16-byte rows).  Same call sites as the _f32 entry points above.  The weight gradient has dedicated bf16 kernels
+ *      for 3x3 and 1x1 layers; other kernel sizes (kernels = 6, the reference's constructor default) run on the tap-table
+ *      weight-gradient kernel with bf16 operand loads (fp32 MFMA arithmetic); the Dense layers stay fp32. */
 int unetrir_conv2d_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w,
                             const float* bias, const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy,
                             unetrir_stream_t stream);

@@ -192,11 +192,11 @@ def test_depth5_graph(U):
 # bf16 storage mode (BASELINE.json configs[1] names bf16).  The oracle restates it exactly: every trunk activation and its
 # gradient are rounded to bf16 where the product stores them (oracle/torch_ref.py storage="bf16"), arithmetic in fp64.
 # ------------------------------------------------------------------------------------------------------------------
-def _bf16_case(U, H, W, F0, B):
-    cfg = R.Config(H, W, F0, 3)
+def _bf16_case(U, H, W, F0, B, k=3):
+    cfg = R.Config(H, W, F0, k)
     Pn = R.init_params(cfg, randomize_all=True, dtype=np.float64)
     spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
-    eng = U.UNetEngine(H, W, B, F0=F0, device=DEV, dtype="bf16")
+    eng = U.UNetEngine(H, W, B, F0=F0, k=k, device=DEV, dtype="bf16")
     eng.load_keras_params(Pn)
     t = lambda a: torch.tensor(a).to(DEV)
     eng.forward(t(spec_in), t(emb), target=t(spec_out), global_batch=B)
@@ -258,6 +258,32 @@ def test_bf16_gradients_as_accurate_as_the_storage_model_allows(U):
     for n, tol in [("head.kernel", 1e-2), ("head.bias", 5e-3), ("dec1.cb1b.gamma", 2e-2)]:
         gt = g_true[n]
         assert float((kg[n].double() - gt).norm()) <= tol * float(gt.norm()), n
+
+
+def test_bf16_storage_with_the_constructor_default_kernel_size_6(U):
+    """bf16 storage with kernels=6 (the reference's constructor default, dl_models/u_net.py:40-45): 6x6 strided / transposed /
+    decoder convolutions on the tap-table kernels, their weight gradients on the tap-table weight-gradient kernel reading the bf16
+    tensors as stored.  Same criteria as for kernels=3: forward within a few bf16 ulps of the oracle's bf16-storage model, gradients
+    as close to the exact ones as that model's are."""
+    cfg, Pn, (spec_in, emb, spec_out), eng = _bf16_case(U, 32, 32, 8, 2, k=6)
+    P = R.to_torch(Pn, torch.float64)
+    pred = R.forward(P, torch.tensor(spec_in).double(), torch.tensor(emb), cfg, True, None, None, None, "bf16")
+    loss = float(R.data_loss(torch.tensor(spec_out).double(), pred, 0.9, 2) + R.reg_loss(P, cfg, 1))
+    assert float((eng.pred.double().cpu() - pred).abs().max()) <= 2e-2
+    got = float(eng.loss_out[0]) + float(eng.reg_out[0])
+    assert abs(got - loss) <= 1e-3 * abs(loss), (got, loss)
+    _, _, _, g_true = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, dtype=torch.float64)
+    _, _, _, g_q = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, dtype=torch.float64, storage="bf16")
+    kg = eng.export_keras_grads()
+    for n, gt in g_true.items():
+        if n.endswith(("cb1.bias", "cb1a.bias", "cb1b.bias")):
+            continue
+        nt = float(gt.norm()) + 1e-30
+        e_hip = float((kg[n].double() - gt).norm()) / nt
+        e_orc = float((g_q[n] - gt).norm()) / nt
+        assert e_hip <= 2.0 * e_orc + 0.02, (n, e_hip, e_orc)
+    m = U.UNet((32, 32, 2), (2, 16), batch_size=2, device=DEV, dtype="bf16")       # constructor defaults, bf16 storage
+    assert m.engine.k == 6 and m.engine.dtype == "bf16"
 
 
 def test_bf16_train_step_reduces_loss_and_is_deterministic(U):

@@ -165,9 +165,11 @@ def test_race_check_detects_a_missing_optimizer_join(monkeypatch):
         tr.step(spec_in, emb, spec_out)
 
 
-def _dp_worker(rank, world, port, out_path, overlap, kind):
+def _dp_worker(rank, world, port, out_path, overlap, kind, B=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if world > 2:
+        torch.set_num_threads(1)                      # eight ranks on the build container's eight cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from _pytest.monkeypatch import MonkeyPatch
@@ -177,7 +179,6 @@ def _dp_worker(rank, world, port, out_path, overlap, kind):
         mpatch = MonkeyPatch()
         rt = SimRuntime()
         cpu_ops.install(mpatch, rt)
-        B = 2
         cfg, eng, tr = _build(rt, B, overlap, world=world, bucket_bytes=8192, kind=kind)
         if rank != 0:
             eng.theta.mul_(0.5)                       # replicas must end up with rank 0's variables
@@ -214,3 +215,66 @@ def test_two_rank_trainer_step_equals_single_process_oracle(tmp_path, overlap, k
         np.testing.assert_allclose(res[r]["losses"].numpy(), np.array(want_l), rtol=1e-5)
     for n in want_p:                                  # replicas stay bit-identical
         assert torch.equal(res[0]["params"][n], res[1]["params"][n]), n
+
+
+def test_eight_rank_trainer_step_equals_single_process_oracle(tmp_path):
+    """The real rank count of BASELINE.json configs[2] (global batch split over 8 replicas, main_training.py:56, :114-117): the
+    product Trainer.step - side-stream schedule, bucket hand-over, bucket-wise Adam, SUM all-reduce, loss normalised by the global
+    batch, l2 terms by the replica count - on eight gloo ranks equals the oracle's single-process training on the concatenated
+    batch; bucket boundaries and hand-over order are the ones the 8-GPU run will see."""
+    world, B = 8, 2
+    out = str(tmp_path / "dp8")
+    port = 31200 + (os.getpid() % 1500)
+    mp.spawn(_dp_worker, args=(world, port, out, True, "unet", B), nprocs=world, join=True)
+    want_p, _, want_l = _oracle_steps(world, B, 2, 1e-3, "unet")
+    res = [torch.load(f"{out}.{r}") for r in range(world)]
+    for r in range(world):
+        assert res[r]["n_buckets"] > 3 and res[r]["n_all_reduce"] == 2 * res[r]["n_buckets"]
+        for n, w in want_p.items():
+            err = float(np.abs(res[r]["params"][n].numpy() - w).max())
+            assert err <= P_ATOL, (r, n, err)
+        np.testing.assert_allclose(res[r]["losses"].numpy(), np.array(want_l), rtol=1e-5)
+    for r in range(1, world):
+        for n in want_p:
+            assert torch.equal(res[0]["params"][n], res[r]["params"][n]), (r, n)
+
+
+def _dropout_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _pytest.monkeypatch import MonkeyPatch
+        import cpu_ops
+        import unet_rir_amd as U
+        from sim_runtime import SimRuntime
+        mpatch = MonkeyPatch()
+        rt = SimRuntime()
+        cpu_ops.install(mpatch, rt)
+        torch.manual_seed(1234)                       # every process seeds alike, as a launcher script would
+        eng = U.UNetEngine(H, W, 2, F0=F0, k=3, device="cpu", runtime=rt, n_replicas=world)
+        base = eng.dropout_seed
+        tr = U.Trainer(eng, lr=1e-3, world_size=world, dropout=True)
+        tr2 = U.Trainer(eng, lr=1e-3, world_size=world, dropout=True)          # a second trainer over the same engine must not offset again
+        m0 = eng.make_dropout_mask().clone()
+        m1 = eng.make_dropout_mask().clone()
+        torch.save({"base": base, "seed": eng.dropout_seed, "m0": m0, "m1": m1, "step": eng._shared["dropout_step"]}, f"{out_path}.{rank}")
+        mpatch.undo()
+        del tr, tr2
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_replicas_draw_independent_dropout_masks(tmp_path):
+    """Dropout(.3) under MirroredStrategy draws per replica (dl_models/u_net.py:260, main_training.py:56): with the process-wide
+    default seed identical in every rank, the trainer offsets each replica's stream by its rank - different masks per replica,
+    different masks per step, the same masks when the run is repeated."""
+    world = 2
+    out = str(tmp_path / "do")
+    mp.spawn(_dropout_worker, args=(world, 30100 + (os.getpid() % 1500), out), nprocs=world, join=True)
+    r0, r1 = (torch.load(f"{out}.{r}") for r in range(world))
+    assert r0["base"] == r1["base"] and r0["seed"] == r0["base"] and r1["seed"] == r0["base"] + 1
+    assert not torch.equal(r0["m0"], r1["m0"]) and not torch.equal(r0["m0"], r0["m1"])
+    assert r0["step"] == r1["step"] == 2
+    assert abs(float((r0["m0"] > 0).float().mean()) - 0.7) < 0.1

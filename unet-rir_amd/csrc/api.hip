@@ -403,7 +403,13 @@ int conv_wgrad_impl(const unetrir_conv_geom* g, const float* x, int ldx, const f
 
 int conv_wgrad_bf16_impl(const unetrir_conv_geom* g, const __bf16* x, int ldx, const __bf16* dy, int lddy, float* dw, float reg,
                          const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (g->k != 3 && g->k != 1) return UNETRIR_EINVAL;       // bf16 weight gradients exist for 3x3 and 1x1 kernels
+    if (g->k != 3 && g->k != 1) {      // other kernel sizes (kernels = 6: the reference's constructor default): the tap-table weight
+                                       // gradient on the bf16 tensors as stored, fp32 MFMA arithmetic
+        WgradArgs a{};
+        wgrad_args(g, ldx, lddy, &a);
+        a.x = (const float*)x; a.dy = (const float*)dy;
+        return launch_igemm_wgrad(a, dw, reg, w, ws, ws_bytes, s, 1);
+    }
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     Wgrad3ArgsH a3{};
     a3.x = x; a3.ldx = ldx; a3.IH = g->H; a3.IW = g->W;

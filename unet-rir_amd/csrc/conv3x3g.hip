@@ -432,14 +432,16 @@ bool conv3x3g_applies(const Conv3Args& a) {
 
 // images at most 16 pixels wide: the paired-image tile (full tiles where the 32-column tile would be half empty)
 bool conv3x3g_pair_applies(const Conv3Args& a) {
-    // config switch conv3x3g_pair: 0 = off, 2 = whenever the shape allows (tests), 1 (default) = only when the paired tiles still
-    // give at least 128 workgroups (1024 -> 1024 at 16 x 16, batch 32: 190 us against 219 us for the tap-table kernel; 512 -> 512
-    // has 64 workgroups and loses 95 : 85)
+    // config switch conv3x3g_pair: 0 = off, 2 = whenever the shape allows (tests), 1 (default) = when the paired tiles give at least
+    // 32 workgroups, counted in the 64-channel tiles the launcher falls back to below 256 workgroups.  (Round 1 asked for 128
+    // workgroups of 128 channels: 512 -> 512 had 64 and lost 95 : 85 us against the tap-table kernel.  With 64-channel tiles,
+    // round 3, batch 32 at 16 x 16: 512 -> 512 61 : 83 us, 256 -> 256 31 : 46, 128 -> 128 18 : 27.)
     const int mode = unetrir_cfg().conv3x3g_pair;
     const size_t pair_bytes = (((size_t)2 * a.H * a.W - 1) * a.ldi + a.C) * 2;
     if (mode == 0 || !conv3x3g_applies(a) || a.W > 16 || a.B < 2 || pair_bytes >= 0x70000000u) return false;
-    const long long wgs = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR) * ((a.N + GBN - 1) / GBN);
-    return mode == 2 || wgs >= 128;
+    const long long ptiles = (long long)((a.B + 1) / 2) * ((a.H + GTR - 1) / GTR);
+    const long long wgs = ptiles * ((a.N & 63) == 0 ? a.N / 64 : (a.N + GBN - 1) / GBN);
+    return mode == 2 || wgs >= 32;
 }
 
 long long conv3x3g_colstat_rows(const Conv3Args& a) {

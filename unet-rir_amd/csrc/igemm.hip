@@ -246,7 +246,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(const IgemmArgs a) {
 #define WG_PIX 32
 #define WG_LDX (WG_COLS + 4)
 
-template <int BR_>   // rows (output channels) per tile: 64 or 128
+// operand loads in the storage type of the activations: fp32, or bf16 widened on the way in (the k x k weight gradients of bf16
+// graphs that have no bf16 kernel of their own - kernels = 6, the reference's constructor default, dl_models/u_net.py:40-45 - run
+// here: fp32 MFMA arithmetic on exactly the stored values)
+typedef __bf16 wg_bf16x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ float4 wg_ld4(const void* base, size_t elem_off);
+template <> __device__ __forceinline__ float4 wg_ld4<float>(const void* base, size_t elem_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+}
+template <> __device__ __forceinline__ float4 wg_ld4<__bf16>(const void* base, size_t elem_off) {
+    const wg_bf16x4 v = *reinterpret_cast<const wg_bf16x4*>(reinterpret_cast<const __bf16*>(base) + elem_off);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+template <int BR_, typename T = float>   // rows (output channels) per tile: 64 or 128
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
     constexpr int MSUB = BR_ / 64;        // BR_=128: waves 2x2 of 64x64; BR_=64: waves 2x2 of 32x64
     constexpr int LDD = BR_ + 4;
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
                 const int py = rem / a.g.PW, px = rem - py * a.g.PW;
                 const int iy = py * SI + dy, ix = px * SI + dx;
                 if ((unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW)
-                    v = *reinterpret_cast<const float4*>(a.x + ((size_t)((long long)n * IH + iy) * IW + ix) * a.g.ldi + c);
+                    v = wg_ld4<T>(a.x, ((size_t)((long long)n * IH + iy) * IW + ix) * a.g.ldi + c);
             }
             rx[j] = v;
         }
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < DPASS; ++j) {
             const long long p = pk + dr + DROWS * j;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nok && p < pk1) v = *reinterpret_cast<const float4*>(a.dy + (size_t)p * a.lddy + n0 + dq * 4);
+            if (nok && p < pk1) v = wg_ld4<T>(a.dy, (size_t)p * a.lddy + n0 + dq * 4);
             rd[j] = v;
         }
     };
@@ -538,7 +551,7 @@ int wgrad_plan(const IgemmGeom& g, int* nsplit, long long* chunks_per_split) {
     return 0;
 }
 
-int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s) {
+int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s, int bf16_operands) {
     int nsplit; long long per;
     wgrad_plan(a.g, &nsplit, &per);
     const size_t nout = (size_t)a.g.N * a.g.wtaps * a.g.C;
@@ -548,7 +561,10 @@ int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* 
     a.chunks_per_split = per;
     const int br = a.g.N > 64 ? 128 : 64;
     const unsigned tiles = (unsigned)(((a.g.N + br - 1) / br) * ((a.g.ntaps * a.g.C + WG_COLS - 1) / WG_COLS));
-    if (br == 128) hipLaunchKernelGGL(igemm_wgrad_kernel<128>, dim3(tiles, nsplit), dim3(256), 0, s, a);
+    if (bf16_operands) {      // a.x / a.dy point at bf16 tensors
+        if (br == 128) hipLaunchKernelGGL((igemm_wgrad_kernel<128, __bf16>), dim3(tiles, nsplit), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((igemm_wgrad_kernel<64, __bf16>), dim3(tiles, nsplit), dim3(256), 0, s, a);
+    } else if (br == 128) hipLaunchKernelGGL(igemm_wgrad_kernel<128>, dim3(tiles, nsplit), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(igemm_wgrad_kernel<64>, dim3(tiles, nsplit), dim3(256), 0, s, a);
     int err = (int)hipGetLastError();
     if (err) return err;

@@ -58,7 +58,7 @@ struct WgradArgs {
 
 int launch_igemm_fwd(const IgemmArgs& a, hipStream_t s);
 int wgrad_plan(const IgemmGeom& g, int* nsplit, long long* chunks_per_split);
-int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s, int bf16_operands = 0);
 int launch_transpose_weight(const float* w, float* wt, int N, int T, int C, hipStream_t s);
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s);
 

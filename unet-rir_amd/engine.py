@@ -236,8 +236,8 @@ class UNetEngine(DeviceCounters):
         self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes
         if F0 % self.PAD:
             raise ValueError(f"number_filters_0 must be a multiple of {self.PAD} for dtype {dtype}")
-        if dtype == "bf16" and k != 3:
-            raise NotImplementedError("the bf16 path implements kernels=3 (weight gradient of 3x3 layers)")
+        # kernels != 3 in bf16 storage (kernels=6 is the reference's constructor default, dl_models/u_net.py:40-45): forward and data
+        # gradients on the tap-table kernels, weight gradients on the tap-table weight-gradient kernel with bf16 operand loads
         if k < 1 or k > 6:
             raise ValueError("kernels must be in 1..6")
         self.H, self.W, self.B, self.F0, self.k, self.depth = H, W, B, F0, k, depth
