@@ -59,36 +59,39 @@ def synthetic_batch(B, H, W, device, seed):
     return spec_in.contiguous(), emb, spec_out.contiguous()
 
 
-def _cpu_steps(F0, H, W, B, budget_s, max_steps=5):
+def _cpu_steps(F0, H, W, B, steps=5, warmups=2, budget_s=150.0):
+    """median of >= 5 timed steps after 2 warm-ups (a step of the benchmarked model at batch 4 takes ~10 s on
+    the GPU box's host cores).  `budget_s` only guards against a pathologically slow host: the count of steps actually timed is
+    reported."""
     from oracle import torch_ref as R
     cfg = R.Config(H, W, F0, 3)
     params = R.init_params(cfg)
     st = R.TrainState(cfg, params, lr=5e-7)
     spec_in, emb, spec_out = R.synthetic_batch(cfg, B)
     spec_in, spec_out, emb = torch.tensor(spec_in), torch.tensor(spec_out), torch.tensor(emb)
-    t0 = time.time()
-    st.step(spec_in, emb, spec_out)               # warm-up
-    warm = time.time() - t0
+    t_begin = time.time()
+    for _ in range(warmups):
+        st.step(spec_in, emb, spec_out)
     times = []
-    while (not times) or (sum(times) + warm + (sum(times) / len(times)) < budget_s and len(times) < max_steps):
+    while len(times) < steps and (len(times) < 1 or time.time() - t_begin < budget_s):
         t0 = time.time()
         st.step(spec_in, emb, spec_out)
         times.append(time.time() - t0)
     times.sort()
-    return B / times[len(times) // 2], len(times)
+    return B / times[len(times) // 2], len(times), warmups
 
 
 def cpu_baseline(F0, H, W):
     """The CPU restatement of the same train step (oracle/torch_ref.py, stock torch CPU ops) on this box's host cores, on
     bounded samples: the benchmarked model at batch 4, and BASELINE.json configs[0] exactly (B=4, F0=16, 256x256, fp32)."""
-    v, n = _cpu_steps(F0, H, W, 4, 30.0)
+    v, n, wu = _cpu_steps(F0, H, W, 4)
     out = {"value": v, "unit": "spectrograms/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"same model (F0={F0}, {H}x{W}) at batch 4, median of {n} steps after 1 warm-up, "
+           "sample": f"same model (F0={F0}, {H}x{W}) at batch 4, median of {n} steps after {wu} warm-ups, "
                      f"oracle/torch_ref.py on torch CPU fp32, os.cpu_count()={os.cpu_count()}"}
-    v1, n1 = _cpu_steps(16, 256, 256, 4, 12.0)
+    v1, n1, wu1 = _cpu_steps(16, 256, 256, 4)
     out["cfg1"] = {"value": v1, "unit": "spectrograms/s",
                    "sample": f"BASELINE.json configs[0] as stated: UNet base=16ch, batch=4 of [2,256,256], fp32, torch CPU; median of "
-                             f"{n1} steps after 1 warm-up"}
+                             f"{n1} steps after {wu1} warm-ups"}
     return out
 
 
@@ -115,6 +118,17 @@ def _by_family(fam):
     counts, fms, ffl = fam
     return {name: {"calls": counts[i], "ms": fms[i], "tflops": (ffl[i] / (fms[i] * 1e-3) / 1e12 if fms[i] > 0 else 0.0)}
             for i, name in ((0, "fwd"), (1, "dgrad"), (2, "wgrad"), (5, "stem_head_dgrad"))}
+
+
+def _dominant(fam, steps, dtype, where):
+    """The dominant kernel's OWN figure (bf16: conv3x3p_bf16_kernel; its launches are counted under family 6 in addition to
+    their forward / data-gradient family): algorithmic FLOPs of its launches / their HIP-event time."""
+    counts, fms, ffl = fam
+    if counts[6] == 0 or fms[6] <= 0:
+        return None
+    ach = ffl[6] / (fms[6] * 1e-3) / 1e12
+    return {"kernel": "conv3x3p_bf16_kernel", "calls_per_step": counts[6] / steps, "avg_call_ms": fms[6] / counts[6],
+            "algorithmic_gflop_per_step": ffl[6] / steps / 1e9, "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS[dtype], "measured_on": where}
 
 
 class Runner:
@@ -219,19 +233,33 @@ class Runner:
 
     def resae_run(self, steps, warmup, dtype="bf16"):
         """BASELINE.json configs[4]: ResAE (main_training.py:130-140: filters 32..256, k 3, s 2, latent 32, n_neurons 1024),
-        batch 32 of [2,256,256], through its boundary class and the Trainer."""
+        batch 32 of [2,256,256], through its boundary class and the Trainer; and the same step captured once into a HIP graph and
+        replayed (single stream: one host call per step)."""
         U = self.U
-        model = U.ResAE((256, 256, 2), (2, 16), (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 16 * 64, name="resae",
-                        batch_size=32, device=self.device, dtype=dtype, overlap=True)
-        tr = U.Trainer(model, lr=5e-7, alpha=0.9)
         spec_in, emb, spec_out = synthetic_batch(32, 256, 256, self.device, 1234)
-        dt, _ = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, 0)
+        out = {}
+        for key, overlap, graph in (("launched", True, False), ("graph", False, True)):
+            model = U.ResAE((256, 256, 2), (2, 16), (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 16 * 64, name="resae",
+                            batch_size=32, device=self.device, dtype=dtype, overlap=overlap)
+            tr = U.Trainer(model, lr=5e-7, alpha=0.9, graph=graph)
+            for _ in range(warmup):
+                tr.step(spec_in, emb, spec_out)
+            self.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.step(spec_in, emb, spec_out)
+            host = time.perf_counter() - t0
+            self.sync()
+            dt = time.perf_counter() - t0
+            out[key] = {"value": 32 * steps / dt, "ms_per_step": dt * 1e3 / steps, "host_ms_per_step": host * 1e3 / steps}
+            params = model.engine.n_params()
+            del tr, model
+            torch.cuda.empty_cache()
         res = {"workload": "BASELINE.json configs[4]: ResAE filters (32,64,128,256), k 3, s 2, latent 32, n_neurons 1024, batch 32 of "
                            "[2,256,256], full train step, " + ("bf16 storage of the convolutional trunk" if dtype == "bf16" else "fp32 storage") + ", side-stream weight gradients",
-               "value": 32 * steps / dt, "unit": "spectrograms/s",
-               "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup, "params": model.engine.n_params(), "dtype": dtype}
-        del tr, model
-        torch.cuda.empty_cache()
+               "value": out["launched"]["value"], "unit": "spectrograms/s", "ms_per_step": out["launched"]["ms_per_step"],
+               "host_ms_per_step": out["launched"]["host_ms_per_step"], "steps": steps, "warmup": warmup, "params": params, "dtype": dtype,
+               "hip_graph_replay_single_stream": out["graph"]}
         return res
 
 
@@ -272,7 +300,14 @@ def roofline_block(main, sub, dtype):
     }
     if overlap:
         r["frac_fwd"] = frac
+    dom = _dominant(main["fam"], steps, dtype, "its forward launches in the timed (side-stream) run" if overlap else
+                    "all its launches (forward + data gradient) in the timed run")
+    if dom is not None:
+        r["dominant_kernel"] = dom
     if sub is not None and sub.get("fam") is not None:
+        dsub = _dominant(sub["fam"], sub["steps"], dtype, "all its launches (forward + data gradient) in the single-stream sub-run")
+        if dsub is not None:
+            r["dominant_kernel_single_stream"] = dsub
         a_all, f_all, ms_a, fl_a, nl_a = _fam_stats(sub["fam"], (0, 1, 2), dtype)
         a_f, f_f, _, _, _ = _fam_stats(sub["fam"], (0,), dtype)
         r["frac_all"] = f_all
@@ -365,8 +400,8 @@ def main():
         if overlap and not args.no_prof:
             sub = run.engine_run(head_dtype, min(args.steps, 5), 2, False)
         if args.dtype == "both":
-            f32_res = run.engine_run("f32", min(args.steps, 5), min(args.warmup, 2), overlap)
-            f32_sub = run.engine_run("f32", 2, 1, False) if overlap and not args.no_prof else None
+            f32_res = run.engine_run("f32", max(args.steps, 20), max(min(args.warmup, 3), 2), overlap)
+            f32_sub = run.engine_run("f32", 5, 2, False) if overlap and not args.no_prof else None
         if (args.f0, args.size, args.depth, args.batch) == (64, 256, 4, 32):
             c4 = run.engine_run("bf16", 3, 2, overlap, prof=False, f0=128, size=512, depth=5, batch=16)
             configs["cfg4_model_1gpu"] = {
@@ -379,8 +414,8 @@ def main():
                             "kernels=3; 9 x 10 bottleneck), batch 32, full train step, bf16 storage - not a BASELINE.json config",
                 "value": rg["value"], "unit": "spectrograms/s", "ms_per_step": rg["ms_per_step"], "steps": rg["steps"],
                 "warmup": rg["warmup"], "params": rg["params"], "dtype": "bf16"}
-            configs["cfg5_resae"] = run.resae_run(5, 2, "bf16")
-            configs["cfg5_resae_fp32"] = run.resae_run(5, 2, "f32")
+            configs["cfg5_resae"] = run.resae_run(20, 3, "bf16")
+            configs["cfg5_resae_fp32"] = run.resae_run(10, 3, "f32")
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()

@@ -459,7 +459,9 @@ int unetrir_stage_h2d(int n, const void* const* src, void* const* pinned, void* 
  *      (one mutex-protected record list); off by default; the second piece of global state. */
 #define UNETRIR_PROF_FAMILIES 8
 enum { UNETRIR_FAM_CONV_FWD = 0, UNETRIR_FAM_CONV_DGRAD = 1, UNETRIR_FAM_CONV_WGRAD = 2,
-       UNETRIR_FAM_BN = 3, UNETRIR_FAM_OTHER = 4 };
+       UNETRIR_FAM_BN = 3, UNETRIR_FAM_OTHER = 4, UNETRIR_FAM_SMALL_CHANNEL = 5,
+       UNETRIR_FAM_DOMINANT = 6 /* launches served by the dominant kernel of the bf16 step (conv3x3p), counted here IN ADDITION to their
+                                   forward / data-gradient family */ };
 int unetrir_prof_enable(int on);      /* 0: off, 1: every family, 2: forward convolutions only (fewer events in the stream) */
 int unetrir_prof_collect(int* counts, double* ms, double* flops);
 

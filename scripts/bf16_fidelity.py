@@ -24,7 +24,7 @@ def build(dtype):
 
 spec_in, emb, spec_out = bench.synthetic_batch(B, H, H, dev, 1234)
 e32, e16 = build("f32"), build("bf16")
-assert torch.equal(e32.theta, e16.theta)
+e16.load_keras_params(e32.export_keras_params())          # identical initial variables (the flat layouts differ by channel padding)
 out = {}
 grads = {}
 for name, eng in (("f32", e32), ("bf16", e16)):

@@ -158,7 +158,7 @@ inline bool geom_ok(const unetrir_conv_geom* g) {
 }
 
 // ---- profiling (the only process-global state in the library; off by default) ----
-struct ProfRec { int fam; hipEvent_t e0, e1; double flops; };
+struct ProfRec { int fam, tag; hipEvent_t e0, e1; double flops; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
 unsigned g_prof_mask = ~0u;       // families that get brackets (unetrir_prof_enable(2): forward convolutions only)
@@ -166,9 +166,10 @@ std::vector<ProfRec> g_prof;
 
 struct ProfScope {
     bool on; ProfRec r; hipStream_t s;
-    ProfScope(int fam, double flops, hipStream_t st) : on(g_prof_on && ((g_prof_mask >> fam) & 1u)), s(st) {
+    // tag: a second family the bracket is ALSO counted under (UNETRIR_FAM_DOMINANT: launches served by the dominant kernel), or -1
+    ProfScope(int fam, double flops, hipStream_t st, int tag = -1) : on(g_prof_on && ((g_prof_mask >> fam) & 1u)), s(st) {
         if (!on) return;
-        r.fam = fam; r.flops = flops;
+        r.fam = fam; r.tag = tag; r.flops = flops;
         hipEventCreate(&r.e0); hipEventCreate(&r.e1);
         hipEventRecord(r.e0, s);
     }
@@ -500,10 +501,16 @@ int unetrir_conv2d_transpose_wgrad_f32(const unetrir_conv_geom* g, const float* 
 }
 
 /* ---- bf16-storage variants: x / dy / y / dx and the weight work copies are bf16, bias fp32, weight gradients fp32 ---- */
+int unetrir_conv3x3_kernel_id_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in);
+// profiling only: launches the dominant kernel of the step (conv3x3p) serves are also counted under UNETRIR_FAM_DOMINANT
+static inline int dominant_tag(const unetrir_conv_geom* g, int dgrad, int ld_in) {
+    if (!g_prof_on || !geom_ok(g) || g->k != 3 || g->stride != 1) return -1;
+    return unetrir_conv3x3_kernel_id_bf16(g, dgrad, ld_in) == UNETRIR_K3_CONV3X3P ? UNETRIR_FAM_DOMINANT : -1;
+}
 int unetrir_conv2d_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* w, const float* bias,
                             const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
     if (!geom_ok(g) || !x || !w || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout) return UNETRIR_EINVAL;
-    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream, dominant_tag(g, 0, ldx));
     return conv_fwd_impl<BF16>(g, (const __bf16*)x, ldx, (const __bf16*)w, bias, (const __bf16*)addend, ldadd, (__bf16*)y, ldy,
                                (hipStream_t)stream);
 }
@@ -525,7 +532,7 @@ int unetrir_conv2d_fwd_packed_bf16(const unetrir_conv_geom* g, const unetrir_bf1
 int unetrir_conv2d_dgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* dy, int lddy, const unetrir_bf16* wt,
                               const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, unetrir_stream_t stream) {
     if (!geom_ok(g) || !dy || !wt || !dx || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin) return UNETRIR_EINVAL;
-    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream, dominant_tag(g, 1, lddy));
     return conv_dgrad_impl<BF16>(g, (const __bf16*)dy, lddy, (const __bf16*)wt, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx,
                                  lddx, (hipStream_t)stream);
 }
@@ -597,7 +604,7 @@ int unetrir_conv2d_fwd_colstat_bf16(const unetrir_conv_geom* g, const unetrir_bf
                                     unetrir_stream_t stream) {
     if (!geom_ok(g) || !x || !w || !y || !colstat || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout || colstat_rows(g, 0, ldx) == 0)
         return UNETRIR_EINVAL;
-    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_FWD), conv_flops(g), (hipStream_t)stream, dominant_tag(g, 0, ldx));
     return conv_fwd_impl<BF16>(g, (const __bf16*)x, ldx, (const __bf16*)w, bias, (const __bf16*)addend, ldadd, (__bf16*)y, ldy,
                                (hipStream_t)stream, colstat);
 }
@@ -608,7 +615,7 @@ int unetrir_conv2d_dgrad_colstat_bf16(const unetrir_conv_geom* g, const unetrir_
     if (!geom_ok(g) || !dy || !wt || !dx || !colstat || (g->Cout & 7) || !ldh_ok(lddy, g->Cout) || lddx < g->Cin ||
         colstat_rows(g, 1, lddy) == 0)
         return UNETRIR_EINVAL;
-    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream);
+    ProfScope ps(conv_family(g, UNETRIR_FAM_CONV_DGRAD), conv_flops(g), (hipStream_t)stream, dominant_tag(g, 1, lddy));
     return conv_dgrad_impl<BF16>(g, (const __bf16*)dy, lddy, (const __bf16*)wt, nullptr, (const __bf16*)addend, ldadd, (__bf16*)dx,
                                  lddx, (hipStream_t)stream, colstat);
 }
@@ -750,6 +757,7 @@ int unetrir_prof_collect(int* counts, double* ms, double* flops) {
         float t = 0.f;
         hipEventElapsedTime(&t, r.e0, r.e1);
         if (r.fam >= 0 && r.fam < UNETRIR_PROF_FAMILIES) { counts[r.fam]++; ms[r.fam] += t; flops[r.fam] += r.flops; }
+        if (r.tag >= 0 && r.tag < UNETRIR_PROF_FAMILIES) { counts[r.tag]++; ms[r.tag] += t; flops[r.tag] += r.flops; }
         hipEventDestroy(r.e0); hipEventDestroy(r.e1);
     }
     g_prof.clear();
