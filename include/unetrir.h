@@ -256,6 +256,14 @@ int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long
                      float beta1, float beta2, float eps, float grad_scale,
                      unetrir_stream_t stream);
 
+/* ---- the other optimizers main_training.py:164-169 selects by name.  SGD(learning_rate): theta -= lr * grad_scale * g.
+ *      Nadam(learning_rate) (tf.keras optimizer_v2: Nesterov Adam with the momentum schedule mu_t = beta1 (1 - 0.5 * 0.96^(0.004 t))):
+ *      m, v as Adam; theta -= lr (c_g g + c_m m) / (sqrt(c_v v) + eps) with c_g = (1 - mu_t) / (1 - prod_{i<=t} mu_i),
+ *      c_m = mu_{t+1} / (1 - prod_{i<=t+1} mu_i), c_v = 1 / (1 - beta2^t), computed by the caller per step. */
+int unetrir_sgd_f32(float* theta, const float* g, long long n, float lr, float grad_scale, unetrir_stream_t stream);
+int unetrir_nadam_f32(float* theta, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                      float c_g, float c_m, float c_v, float grad_scale, unetrir_stream_t stream);
+
 /* ---- step counters in DEVICE memory, so that a whole train step can be captured once into a HIP graph and replayed: the values
  *      that change from step to step (Adam's bias-corrected rate, the dropout draw number) are then read by the kernels instead
  *      of being launch arguments.

@@ -394,6 +394,28 @@ def adam_update(theta, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-7):
     return theta - lr_t * m / (v.sqrt() + eps), m, v
 
 
+def sgd_update(theta, g, lr):
+    """tf.keras.optimizers.SGD(learning_rate=lr) without momentum (main_training.py:166-167)."""
+    return theta - lr * g
+
+
+def nadam_update(theta, g, m, v, t, lr, m_schedule, b1=0.9, b2=0.999, eps=1e-7):
+    """tf.keras.optimizers.Nadam (main_training.py:164-165) as TF 2.x's optimizer_v2 implements it (Dozat's Nesterov Adam with the
+    momentum schedule mu_t = beta_1 (1 - 0.5 * 0.96^(0.004 t)); m_schedule is the running product of the mu_t, 1.0 before the first
+    step).  Restated from the published algorithm: PARITY UNPINNED like the rest of the oracle."""
+    mu_t = b1 * (1.0 - 0.5 * 0.96 ** (0.004 * t))
+    mu_t1 = b1 * (1.0 - 0.5 * 0.96 ** (0.004 * (t + 1)))
+    ms_new = m_schedule * mu_t
+    ms_next = ms_new * mu_t1
+    g_prime = g / (1.0 - ms_new)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    m_prime = m / (1.0 - ms_next)
+    v_prime = v / (1.0 - b2 ** t)
+    m_bar = (1.0 - mu_t) * g_prime + mu_t1 * m_prime
+    return theta - lr * m_bar / (v_prime.sqrt() + eps), m, v, ms_new
+
+
 class TrainState:
     """Holds parameters + Adam slots for repeated oracle train steps (CPU baseline)."""
 

@@ -335,6 +335,18 @@ class CpuOps:
         r = float(coef * (x.to(D) ** 2).sum())
         out[0] = (float(out[0]) + r) if accumulate else r
 
+    def sgd(self, theta, g, lr, grad_scale=1.0):
+        self.rt.touch([theta, g], [theta], "sgd")
+        theta.copy_((theta.to(D) - lr * grad_scale * g.to(D)).float())
+
+    def nadam(self, theta, g, m, v, lr, beta1, beta2, eps, c_g, c_m, c_v, grad_scale=1.0):
+        self.rt.touch([theta, g, m, v], [theta, m, v], "nadam")
+        gg = g.to(D) * grad_scale
+        m_ = beta1 * m.to(D) + (1 - beta1) * gg
+        v_ = beta2 * v.to(D) + (1 - beta2) * gg * gg
+        theta.copy_((theta.to(D) - lr * (c_g * gg + c_m * m_) / ((c_v * v_).sqrt() + eps)).float())
+        m.copy_(m_.float()); v.copy_(v_.float())
+
     def adam(self, theta, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         self.rt.touch([theta, g, m, v], [theta, m, v], "adam")
         gg = g.to(D) * grad_scale
@@ -342,6 +354,10 @@ class CpuOps:
         v_ = beta2 * v.to(D) + (1 - beta2) * gg * gg
         theta.copy_((theta.to(D) - lr_t * m_ / (v_.sqrt() + eps)).float())
         m.copy_(m_.float()); v.copy_(v_.float())
+
+
+def _noop():
+    pass
 
 
 def _with_grad(fn):

@@ -863,3 +863,41 @@ def test_pw1x1_kernel_against_the_tap_table_kernel_and_the_oracle(U, case):
         want_t = R.conv2d_transpose_same(xo, k_hwoi, a["bias"].double().cpu(), s)
         got_t = a["yt"].double().cpu().permute(0, 3, 1, 2)
         assert float((got_t - want_t).abs().max()) <= 1e-2 * float(want_t.abs().max())
+
+
+def test_sgd_and_nadam_steps_against_the_oracle(U):
+    """The optimizers main_training.py:164-169 selects besides Adam: three steps of SGD(learning_rate) and of Nadam(learning_rate)
+    (momentum schedule, running product of the schedule) through Trainer-level state (engine.adam_begin / adam_range) against the
+    oracle's restatement."""
+    ops = U.ops
+    n = 1000 + 3                                     # not a multiple of 4: the tail path
+    gen = torch.Generator(); gen.manual_seed(9)
+    theta0 = torch.randn(n, generator=gen)
+    gs = [torch.randn(n, generator=gen) * 0.1 for _ in range(3)]
+    lr = 1e-2
+    # SGD
+    th = theta0.clone().to(DEV)
+    want = theta0.double()
+    for g in gs:
+        ops.sgd(th, g.to(DEV), lr)
+        want = R.sgd_update(want, g.double(), lr)
+    torch.cuda.synchronize()
+    close(th, want, 1e-6, "sgd")
+    # Nadam through the engine's step bookkeeping
+    eng = U.UNetEngine(32, 32, 2, F0=8, device=DEV)
+    tr = U.Trainer(eng, lr=lr, optimizer="Nadam")
+    assert eng.optimizer == "nadam" and not tr.use_graph
+    g0 = torch.Generator(); g0.manual_seed(1)
+    eng.reset_parameters(g0)
+    t_ref, m, v, ms = eng.theta.double().cpu(), torch.zeros(eng.theta.numel(), dtype=torch.float64), torch.zeros(eng.theta.numel(), dtype=torch.float64), 1.0
+    for step in range(1, 4):
+        gr = torch.randn(eng.grad.numel(), generator=gen) * 0.1
+        eng.grad.copy_(gr.to(DEV))
+        eng.adam_step(lr)
+        t_ref, m, v, ms = R.nadam_update(t_ref, gr.double(), m, v, step, lr, ms)
+    torch.cuda.synchronize()
+    assert eng.adam_t == 3 and abs(eng._shared["m_schedule"] - ms) <= 1e-15
+    close(eng.theta, t_ref, 2e-6, "nadam theta")
+    close(eng.adam_m, m, 2e-6, "nadam m")
+    with pytest.raises(ValueError):
+        U.Trainer(eng, optimizer="lamb")

@@ -44,7 +44,7 @@ def _oracle(kind):
     return cfg, R.init_params(cfg, randomize_all=True, dtype=np.float64), lg
 
 
-def _oracle_steps(world, B, n_steps, lr, kind="unet"):
+def _oracle_steps(world, B, n_steps, lr, kind="unet", opt="adam"):
     """The reference semantics on one process: per-replica gradients summed, one Adam per step."""
     from oracle import torch_ref as R
     cfg, params, loss_and_grads = _oracle(kind)
@@ -53,6 +53,7 @@ def _oracle_steps(world, B, n_steps, lr, kind="unet"):
     v_ = {k: torch.zeros(v.shape, dtype=torch.float64) for k, v in params.items()}
     spec_in, emb, spec_out = R.synthetic_batch(R.Config(H, W), B * world)
     losses, grads_first = [], None
+    ms = 1.0
     for t in range(1, n_steps + 1):
         total, loss = None, 0.0
         for r in range(world):
@@ -63,9 +64,16 @@ def _oracle_steps(world, B, n_steps, lr, kind="unet"):
         if grads_first is None:
             grads_first = total
         losses.append(loss)
+        ms_next = ms
         for k in params:
-            new, m[k], v_[k] = R.adam_update(torch.tensor(params[k]), total[k], m[k], v_[k], t, lr)
+            if opt == "sgd":
+                new = R.sgd_update(torch.tensor(params[k]), total[k], lr)
+            elif opt == "nadam":
+                new, m[k], v_[k], ms_next = R.nadam_update(torch.tensor(params[k]), total[k], m[k], v_[k], t, lr, ms)
+            else:
+                new, m[k], v_[k] = R.adam_update(torch.tensor(params[k]), total[k], m[k], v_[k], t, lr)
             params[k] = new.numpy()
+        ms = ms_next
     return params, grads_first, losses
 
 
@@ -278,3 +286,23 @@ def test_replicas_draw_independent_dropout_masks(tmp_path):
     assert not torch.equal(r0["m0"], r1["m0"]) and not torch.equal(r0["m0"], r0["m1"])
     assert r0["step"] == r1["step"] == 2
     assert abs(float((r0["m0"] > 0).float().mean()) - 0.7) < 0.1
+
+
+@pytest.mark.parametrize("opt", ["sgd", "nadam"])
+def test_other_optimizers_of_the_reference_on_the_product_schedule(monkeypatch, opt):
+    """main_training.py:164-169 selects Nadam / SGD / Adam by name: the product step with optimizer="nadam" / "sgd" (side-stream
+    schedule, bucket-wise optimizer) against the oracle's restatement, two steps."""
+    import cpu_ops
+    import unet_rir_amd as U
+    from sim_runtime import SimRuntime
+    from oracle import torch_ref as R
+    rt = SimRuntime()
+    cpu_ops.install(monkeypatch, rt)
+    B = 2
+    cfg, eng, _ = _build(rt, B, True, bucket_bytes=8192)
+    tr = U.Trainer(eng, lr=LR, dropout=False, bucket_bytes=8192, optimizer=opt)
+    spec_in, emb, spec_out = (torch.tensor(a) for a in R.synthetic_batch(cfg, B))
+    want_p, _, want_l = _oracle_steps(1, B, 2, LR, "unet", opt)
+    losses = [tr.step(spec_in, emb, spec_out, return_loss=True) for _ in range(2)]
+    np.testing.assert_allclose(np.array(losses), np.array(want_l), rtol=1e-5)
+    _check_params(eng, want_p)

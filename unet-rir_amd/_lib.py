@@ -172,6 +172,9 @@ _SIGS = {
                                               c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_sigmoid_loss_ex_bf16": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_sgd_f32": (C.c_int, [c_f32p, c_f32p, C.c_longlong, C.c_float, C.c_float, c_stream]),
+    "unetrir_nadam_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, c_stream]),
     "unetrir_step_advance": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, c_stream]),
     "unetrir_adam_dev_f32": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_longlong, c_f32p, c_stream]),
     "unetrir_dropout_mask_dev_f32": (C.c_int, [c_f32p, C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p, C.c_ulonglong, c_stream]),

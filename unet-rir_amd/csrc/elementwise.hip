@@ -651,6 +651,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ theta, co
     }
 }
 
+// The other two optimizers main_training.py:164-169 can select.  SGD: theta -= lr * g.  Nadam (tf.keras optimizer_v2): the moments
+// of Adam, the step lr * (c_g g + c_m m) / (sqrt(c_v v) + eps) with the step-dependent coefficients computed on the host
+// (momentum schedule mu_t = beta_1 (1 - 0.5 * 0.96^(0.004 t)): c_g = (1 - mu_t) / (1 - prod mu), c_m = mu_{t+1} / (1 - prod mu * mu_{t+1}),
+// c_v = 1 / (1 - beta_2^t)).
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ theta, const float* __restrict__ g, long long n, float lr, float gs) {
+    const long long n4 = n / 4, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 t = reinterpret_cast<float4*>(theta)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        t.x -= lr * gs * gg.x; t.y -= lr * gs * gg.y; t.z -= lr * gs * gg.z; t.w -= lr * gs * gg.w;
+        reinterpret_cast<float4*>(theta)[i] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (long long i = n4 * 4; i < n; ++i) theta[i] -= lr * gs * g[i];
+}
+
+__global__ __launch_bounds__(256) void nadam_kernel(float* __restrict__ theta, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                    float cg, float cm, float cv, float gs) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gk = g[i] * gs;
+        const float mk = b1 * m[i] + (1.f - b1) * gk;
+        const float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        m[i] = mk; v[i] = vk;
+        theta[i] -= lr * (cg * gk + cm * mk) / (sqrtf(cv * vk) + eps);
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------------
@@ -884,6 +913,20 @@ int unetrir_adam_f32(float* theta, const float* g, float* m, float* v, long long
     if (!theta || !g || !m || !v || n <= 0) return UNETRIR_EINVAL;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n,
                        lr_t, beta1, beta2, eps, grad_scale, (const float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int unetrir_sgd_f32(float* theta, const float* g, long long n, float lr, float grad_scale, unetrir_stream_t stream) {
+    if (!theta || !g || n <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, n, lr, grad_scale);
+    return (int)hipGetLastError();
+}
+
+int unetrir_nadam_f32(float* theta, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                      float c_g, float c_m, float c_v, float grad_scale, unetrir_stream_t stream) {
+    if (!theta || !g || !m || !v || n <= 0) return UNETRIR_EINVAL;
+    hipLaunchKernelGGL(nadam_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, theta, g, m, v, n, lr, beta1, beta2,
+                       eps, c_g, c_m, c_v, grad_scale);
     return (int)hipGetLastError();
 }
 

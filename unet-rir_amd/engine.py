@@ -187,29 +187,45 @@ class DeviceCounters:
         self._shared["dropout_step"] += 1
         return buf
 
-    def _adam(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
+    optimizer = "adam"           # "adam" | "nadam" | "sgd" (main_training.py:164-169); set through trainer.Trainer(optimizer=)
+
+    def _adam(self, lo, hi, *args):
         dev = self._dev()
         th, g, m, v = (self.theta, self.grad, self.adam_m, self.adam_v) if lo is None else \
             (self.theta[lo:hi], self.grad[lo:hi], self.adam_m[lo:hi], self.adam_v[lo:hi])
-        if dev is None:
-            ops.adam(th, g, m, v, lr_t, beta1, beta2, eps, grad_scale)
+        if args[0] == "sgd":
+            ops.sgd(th, g, args[1], args[2])
+        elif args[0] == "nadam":
+            ops.nadam(th, g, m, v, *args[1:])
+        elif dev is None:
+            ops.adam(th, g, m, v, *args)
         else:
             ops.adam_dev(th, g, m, v, dev["hyper"])
         self.t_dirty = True
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-        """tf.keras Adam over the whole flat parameter buffer in one launch (main_training.py:268)."""
+        """One optimizer step over the whole flat parameter buffer in one launch (optimizer.apply_gradients, main_training.py:268)."""
         self._adam(None, None, *self.adam_begin(lr, beta1, beta2, eps, grad_scale))
 
     def adam_begin(self, lr, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-        """Advance the step count once and return the arguments of adam_range for this step (bucket-wise optimizer)."""
+        """Advance the step count once and return the arguments of adam_range for this step (bucket-wise optimizer).  Adam: the
+        bias-corrected rate; Nadam: the momentum-schedule coefficients of this step (the running product of the schedule lives
+        beside the step count); SGD: the rate."""
         self.adam_t += 1
         t = self.adam_t
+        if self.optimizer == "sgd":
+            return ("sgd", lr, grad_scale)
+        if self.optimizer == "nadam":
+            mu_t = beta1 * (1.0 - 0.5 * 0.96 ** (0.004 * t))
+            mu_t1 = beta1 * (1.0 - 0.5 * 0.96 ** (0.004 * (t + 1)))
+            ms_new = self._shared.get("m_schedule", 1.0) * mu_t
+            self._shared["m_schedule"] = ms_new
+            return ("nadam", lr, beta1, beta2, eps, (1.0 - mu_t) / (1.0 - ms_new), mu_t1 / (1.0 - ms_new * mu_t1), 1.0 / (1.0 - beta2 ** t), grad_scale)
         return (lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t), beta1, beta2, eps, grad_scale)
 
-    def adam_range(self, lo, hi, lr_t, beta1, beta2, eps, grad_scale):
-        """Adam on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
-        self._adam(lo, hi, lr_t, beta1, beta2, eps, grad_scale)
+    def adam_range(self, lo, hi, *args):
+        """The optimizer on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
+        self._adam(lo, hi, *args)
 
 
 class UNetEngine(DeviceCounters):
@@ -440,6 +456,7 @@ class UNetEngine(DeviceCounters):
             for n, b in self.moving.items():
                 b.fill_(1.0 if n.endswith("variance") else 0.0)
             self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t = 0
+            self._shared["m_schedule"] = 1.0
         self.t_dirty = True
 
     # ---- conversion to / from the reference's own (Keras) layouts -----------------------------

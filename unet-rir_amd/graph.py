@@ -552,6 +552,7 @@ class GraphEngine(DeviceCounters):
             for n, b in self.moving.items():
                 b.fill_(1.0 if n.endswith("variance") else 0.0)
             self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t = 0
+            self._shared["m_schedule"] = 1.0
         self.t_dirty = True
 
     # ------------------------------------------------------------------ step pieces

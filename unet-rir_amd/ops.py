@@ -507,6 +507,17 @@ def adam(theta, g, m, v, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0)
                                       float(grad_scale), _stream()), "adam")
 
 
+def sgd(theta, g, lr, grad_scale=1.0):
+    """tf.keras.optimizers.SGD(learning_rate) step (main_training.py:166-167)."""
+    check(_lib.lib().unetrir_sgd_f32(_p(theta), _p(g), theta.numel(), float(lr), float(grad_scale), _stream()), "sgd")
+
+
+def nadam(theta, g, m, v, lr, beta1, beta2, eps, c_g, c_m, c_v, grad_scale=1.0):
+    """tf.keras.optimizers.Nadam step (main_training.py:164-165) with the step's schedule coefficients (engine.DeviceCounters)."""
+    check(_lib.lib().unetrir_nadam_f32(_p(theta), _p(g), _p(m), _p(v), theta.numel(), float(lr), beta1, beta2, eps, float(c_g), float(c_m),
+                                       float(c_v), float(grad_scale), _stream()), "nadam")
+
+
 def adam_dev(theta, g, m, v, hyper):
     """adam() with its five scalars read from device memory (hyper: fp32 [>=5], written by step_advance): HIP-graph replay."""
     check(_lib.lib().unetrir_adam_dev_f32(_p(theta), _p(g), _p(m), _p(v), theta.numel(), _p(hyper), _stream()), "adam_dev")

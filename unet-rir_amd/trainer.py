@@ -126,7 +126,7 @@ class Trainer:
     """
 
     def __init__(self, model, lr=5e-7, alpha=0.9, world_size=1, group=None, bucket_bytes=32 << 20, dropout=True, force_dp=False,
-                 sigmoid_loss=False, diff_loss=False, beta=0.5, graph=False, dropout_seed=None):
+                 sigmoid_loss=False, diff_loss=False, beta=0.5, graph=False, dropout_seed=None, optimizer="adam"):
         """force_dp: run the bucketed all-reduce path even at world_size 1 (needs an initialised process group; rehearsal).
         sigmoid_loss / diff_loss / beta: the switches of compute_loss (main_training.py:38-40, :214-222; both False in the
         reference's live configuration): column weights sigmoid(beta, ...) of preprocess.py:116-121 on the phase term, and the
@@ -134,6 +134,7 @@ class Trainer:
         graph: capture `step` once into a HIP graph (after one ordinary step that is undone) and replay it - one host call per
         step instead of several hundred launches; single-replica steps without an externally supplied dropout mask only
         (anything else runs the ordinary way).
+        optimizer: "adam" (the live configuration), "nadam" or "sgd" - main_training.py:164-169 selects by substring, so does this.
         dropout_seed: base seed of the Dropout streams; replica r draws from stream seed + r (independent masks per replica, as
         under MirroredStrategy).  Default: the engine's own seed (torch.initial_seed())."""
         self.module = None
@@ -161,7 +162,11 @@ class Trainer:
             engine._seed_offset_by_rank = True
         engine.loss_diff = bool(diff_loss)
         engine.loss_phase_weight = phase_weight(beta, engine.W).to(engine.device) if sigmoid_loss else None
-        self.use_graph = bool(graph) and not dp
+        opt = str(optimizer).lower()
+        engine.optimizer = "nadam" if "nadam" in opt else ("sgd" if "sgd" in opt else "adam")
+        if "adam" not in opt and "sgd" not in opt:
+            raise ValueError("optimizer must name adam, nadam or sgd (main_training.py:164-169)")
+        self.use_graph = bool(graph) and not dp and engine.optimizer == "adam"
         self._graphs, self._g_in = {}, None
         # With a side stream in the engine (overlap_wgrad) the optimizer also leaves the critical path: Adam runs bucket by
         # bucket on a third stream as soon as a bucket's gradients are final (and, data-parallel, all-reduced), while the
@@ -375,6 +380,7 @@ class CheckpointManager:
         state = {
             "format": 1, "epoch": epoch, "lr": self.trainer.lr, "adam_t": eng.adam_t,
             "dropout_step": int(eng._shared["dropout_step"]), "dropout_seed": int(eng.dropout_seed),
+            "optimizer": eng.optimizer, "m_schedule": float(eng._shared.get("m_schedule", 1.0)),
             "layout": [(k, tuple(s_.shape), int(s_.offset)) for k, s_ in eng.specs.items()],
             "theta": eng.theta.detach().cpu(), "adam_m": eng.adam_m.detach().cpu(), "adam_v": eng.adam_v.detach().cpu(),
             "moving": {k: v.detach().cpu() for k, v in eng.moving.items()},
@@ -403,6 +409,8 @@ class CheckpointManager:
         if "dropout_step" in state:              # the Dropout stream continues where it stopped (older checkpoints: from draw 0)
             eng._shared["dropout_step"] = int(state["dropout_step"])
             eng.dropout_seed = int(state["dropout_seed"])
+        if "m_schedule" in state:
+            eng._shared["m_schedule"] = float(state["m_schedule"])
         eng.t_dirty = True
         eng.sync_device_counters()
         return state.get("epoch")
