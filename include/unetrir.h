@@ -78,10 +78,11 @@ int unetrir_abi_version(void);
  *        conv3x3p       UNETRIR_CONV3X3P       bf16 persistent form of conv3x3g for layers with >= 512 tiles (conv3x3p.hip)
  *        upconv3x3q     UNETRIR_UPCONV3X3Q     bf16 persistent form of upconv3x3g for layers with >= 512 tiles (upconv3x3q.hip)
  *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup)
- *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip) */
+ *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip)
+ *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1;
+        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);
@@ -375,7 +376,7 @@ int unetrir_conv2d_dgrad_colstat_bf16(const unetrir_conv_geom* g, const unetrir_
                                       const unetrir_bf16* addend, int ldadd, unetrir_bf16* dx, int lddx, float* colstat,
                                       unetrir_stream_t stream);
 /* The same for every other convolution of the graphs (1x1 layers, strided layers, the tap-table path of small images): the
- * implicit-GEMM kernel emits one row per 128-pixel tile of its launch.  unetrir_conv2d_colstat_rows_bf16 answers for these
+ * implicit-GEMM kernel emits one row per pixel tile (128 or 64 pixels) of its launch.  unetrir_conv2d_colstat_rows_bf16 answers for these
  * layers too (0 only where the serving kernel has none: 3x3 stride-2 forward, strided data gradients).  Conv2DTranspose
  * forward (dl_models/res_ae.py:310-371: every decoder convolution of the residual graph sits in front of a BatchNormalization):
  * stride 1 = one row per 128-pixel tile; stride 2 (1x1 'valid', 6x6) = the four output-parity classes, each with its own row

@@ -901,3 +901,62 @@ def test_sgd_and_nadam_steps_against_the_oracle(U):
     close(eng.adam_m, m, 2e-6, "nadam m")
     with pytest.raises(ValueError):
         U.Trainer(eng, optimizer="lamb")
+
+
+@pytest.mark.parametrize("case", [(4, 36, 40, 128, 128, 3, 1), (3, 18, 20, 64, 96, 3, 1), (5, 9, 10, 256, 128, 3, 1), (2, 20, 24, 64, 128, 6, 1),
+                                  (3, 18, 20, 64, 64, 6, 2), (2, 9, 11, 32, 64, 3, 2), (2, 12, 16, 24, 40, 5, 1)])
+def test_small_problem_tap_table_kernel_equals_the_general_one(U, case):
+    """igemm2 (64-pixel tiles, two K chunks in flight: the reference geometry's small levels, main_training.py:27; 6 x 6 kernels,
+    dl_models/u_net.py:40-45) against the general tap-table kernel on the same layers: the same MFMA chain over the same K order,
+    so identical bits - Conv2D forward (bias, addend, fused column statistics), data gradient, Conv2DTranspose forward and data
+    gradient (stride 2: the four parity classes in one grid), odd sizes, channel counts that are not multiples of 64."""
+    ops = U.ops
+    B, H, W, Ci, Co, k, s = case
+    gen = torch.Generator(device=DEV); gen.manual_seed(H * 100 + Ci + k)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    old = ops.get_config()
+    out = {}
+    try:
+        for on in (1, 0):
+            ops.set_config(igemm2=on, conv3x3=0, conv3x3g_pair=0, conv3x3d=0, upconv3x3g=0, upconv3x3q=0)     # everything on the tap-table path
+            gen.manual_seed(H * 100 + Ci + k)
+            g = ops.geom(B, H, W, Ci, Co, k, s)
+            Ho, Wo = -(-H // s), -(-W // s)
+            x = ops.Act(rnd(B, H, W, Ci + 8), 0, Ci)
+            w, wt = (rnd(Co, k * k, Ci).float() * 0.2).to(torch.bfloat16), (rnd(Ci, k * k, Co).float() * 0.2).to(torch.bfloat16)
+            bias = torch.rand(Co, device=DEV, generator=gen) - 0.5
+            add = ops.Act(rnd(B, Ho, Wo, Co))
+            y = ops.Act(torch.full((B, Ho, Wo, Co + 8), 3.0, dtype=torch.bfloat16, device=DEV), 0, Co)
+            ops.conv2d_fwd(g, x, w, bias, y, addend=add)
+            rows = ops.conv2d_colstat_rows(g, 0, x)
+            y2 = ops.Act(torch.empty((B, Ho, Wo, Co), dtype=torch.bfloat16, device=DEV))
+            cst = None
+            if rows:
+                cst = torch.full((rows, Co, 2), 7.0, device=DEV)
+                ops.conv2d_fwd_colstat(g, x, w, bias, y2, cst)
+            else:
+                ops.conv2d_fwd(g, x, w, bias, y2)
+            gy = ops.Act(rnd(B, Ho, Wo, Co))
+            dx = ops.Act(torch.full((B, H, W, Ci), 5.0, dtype=torch.bfloat16, device=DEV))
+            ops.conv2d_dgrad(g, gy, wt, dx)
+            # the transposed layer Ci -> Co on the H x W grid
+            gt = ops.geom(B, H, W, Ci, Co, k, s)
+            wtr, wprim = (rnd(Co, k * k, Ci).float() * 0.2).to(torch.bfloat16), (rnd(Ci, k * k, Co).float() * 0.2).to(torch.bfloat16)
+            yt = ops.Act(torch.empty((B, H * s, W * s, Co), dtype=torch.bfloat16, device=DEV))
+            ops.conv2d_transpose_fwd(gt, x, wtr, bias, yt)
+            gyt = ops.Act(rnd(B, H * s, W * s, Co))
+            dxt = ops.Act(torch.empty((B, H, W, Ci), dtype=torch.bfloat16, device=DEV))
+            ops.conv2d_transpose_dgrad(gt, gyt, wprim, dxt)
+            torch.cuda.synchronize()
+            out[on] = dict(y=y.base.clone(), y2=y2.base.clone(), cs=None if cst is None else cst.double().sum(0), dx=dx.base.clone(),
+                           yt=yt.base.clone(), dxt=dxt.base.clone(), rows=rows)
+    finally:
+        ops.set_config(**old)
+    for kk in ("y", "y2", "dx", "yt", "dxt"):
+        assert torch.equal(out[1][kk], out[0][kk]), (kk, float((out[1][kk].float() - out[0][kk].float()).abs().max()))
+    assert float(out[1]["y"][..., Co:].float().min()) == 3.0
+    if out[1]["cs"] is not None:
+        td = out[1]["y2"].double()
+        close(out[1]["cs"][:, 0], td.sum(dim=(0, 1, 2)), 2e-6, "colstat sum")
+        close(out[1]["cs"][:, 1], (td * td).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares")
+        assert out[1]["rows"] >= out[0]["rows"]                   # 64-pixel tiles: at least as many rows as the 128-pixel kernel

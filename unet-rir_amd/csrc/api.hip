@@ -31,6 +31,7 @@ unetrir_config load_config() {
     c.dyn_tiles = env_int("UNETRIR_DYN_TILES", 1);
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     c.pw1x1 = env_int("UNETRIR_PW1X1", 1);
+    c.igemm2 = env_int("UNETRIR_IGEMM2", 1);
     return c;
 }
 unetrir_config& config_storage() {
@@ -348,7 +349,7 @@ int conv_dgrad_impl(const unetrir_conv_geom* g, const typename P::T* dy, int ldd
             }
             a.g.ntaps = nt; a.g.ooy = ay; a.g.oox = ax;
             if constexpr (P::is_bf16) {      // column statistics: the four classes write consecutive row ranges
-                if (colstat) a.colstat = colstat + (size_t)(ay * 2 + ax) * igemm_colstat_rows((long long)g->B * a.g.PH * a.g.PW) * g->Cin * 2;
+                if (colstat) a.colstat = colstat + (size_t)(ay * 2 + ax) * igemm_colstat_rows((long long)g->B * a.g.PH * a.g.PW, g->Cin, 4) * g->Cin * 2;
             }
             cls[ay * 2 + ax] = a;
         }
@@ -544,8 +545,8 @@ static long long colstat_rows(const unetrir_conv_geom* g, int dgrad, int ld_in) 
     const Same sy = same_geom(g->H, g->k, g->stride), sx = same_geom(g->W, g->k, g->stride);
     // rows the tap-table kernel writes: one per 128-pixel tile of its iteration grid (forward: the output grid; data gradient at
     // stride 1: the input grid).  Strided data gradients have no fused statistics through this entry point.
-    const long long igemm_rows = dgrad ? (g->stride == 1 ? igemm_colstat_rows((long long)g->B * g->H * g->W) : 0)
-                                       : igemm_colstat_rows((long long)g->B * sy.out * sx.out);
+    const long long igemm_rows = dgrad ? (g->stride == 1 ? igemm_colstat_rows((long long)g->B * g->H * g->W, g->Cin) : 0)
+                                       : igemm_colstat_rows((long long)g->B * sy.out * sx.out, g->Cout);
     if (g->k == 1) {          // the register-streaming 1x1 kernel: one row per persistent workgroup
         const PwArgs pw = dgrad ? pw_dgrad_args(g, nullptr, ld_in, nullptr, nullptr, nullptr, 0, nullptr, g->Cin, nullptr)
                                 : pw_fwd_args(g, nullptr, ld_in, nullptr, nullptr, nullptr, 0, nullptr, g->Cout, nullptr);
@@ -579,7 +580,7 @@ static long long colstat_rows_transpose(const unetrir_conv_geom* g, int ld_in) {
         const PwArgs pw = pw_dgrad_args(&c, nullptr, ld_in, nullptr, nullptr, nullptr, 0, nullptr, g->Cout, nullptr);
         if (pw1x1_applies(pw)) return pw1x1_colstat_rows(pw);
     }
-    return 4 * igemm_colstat_rows((long long)g->B * g->H * g->W);
+    return 4 * igemm_colstat_rows((long long)g->B * g->H * g->W, g->Cout, 4);
 }
 long long unetrir_conv2d_colstat_rows_bf16(const unetrir_conv_geom* g, int dgrad, int ld_in) { return colstat_rows(g, dgrad, ld_in); }
 

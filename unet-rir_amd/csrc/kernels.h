@@ -86,8 +86,16 @@ struct IgemmArgsH {
     float* colstat;        // nullable: [pixel tile][N][2] per-channel (sum, sum of squares) of the stored bf16 output, one row per
                            // 128-pixel tile of the launch (row = tile index); requires addend == nullptr
 };
-// rows of column statistics one tap-table launch writes (= its 128-pixel tiles)
-inline long long igemm_colstat_rows(long long tile_pixels) { return (tile_pixels + 127) / 128; }
+// The tap-table launch for small problems (igemm2_bf16.hip): pixel-tile height it would use for an iteration grid of M pixels, N
+// output channels and ncls launches sharing one grid (1, or the 4 parity classes of a stride-2 transposed layer); 0 = not taken
+// (switch off / too large): the general kernel with 128-pixel tiles.
+int igemm_bf16_tile_m(long long M, int N, int ncls);
+int launch_igemm2_fwd_bf16(const IgemmArgsH* a, int ncls, hipStream_t s);
+// rows of column statistics one tap-table launch writes (= its pixel tiles)
+inline long long igemm_colstat_rows(long long M, int N, int ncls = 1) {
+    const int bm = igemm_bf16_tile_m(M, N, ncls);
+    return (M + (bm ? bm : 128) - 1) / (bm ? bm : 128);
+}
 struct Wgrad3ArgsH {
     const __bf16* x; int ldx; int IH, IW;
     const __bf16* dy; int lddy; int OH, OW;
