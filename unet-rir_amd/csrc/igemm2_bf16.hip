@@ -5,7 +5,7 @@
 // 128 x 128 tiles with ONE K chunk in flight suit large grids; on a 36 x 40 level there are 360 workgroups for 256 CUs, each
 // alone on its CU, and every one of its 18 K chunks pays a full global-memory round trip: 46 us for 13.6 GFLOP (0.3 PFLOP/s).
 // Same arithmetic here (v_mfma_f32_32x32x16_bf16 over the same K order: identical bits), re-shaped for few pixels:
-//   * 64-pixel tiles (BM = 64) when 128-pixel tiles would leave CUs without a second workgroup: four times the workgroups, 37 KB
+//   * 64-pixel tiles (BM = 64) when 128-pixel tiles would not even give every CU one workgroup: four times the workgroups, 37 KB
 //     of LDS each, so three to four share a CU and cover each other's memory latency;
 //   * TWO K chunks in flight per workgroup: the registers of chunk c + 1 go to the second LDS buffer while chunk c is computed,
 //     and are re-loaded for chunk c + 3 at once - one barrier per chunk instead of two, loads issued two chunks ahead;
@@ -13,6 +13,7 @@
 //   * the same epilogue: bias, optional addend, 16-byte stores through an LDS staging tile, fused column statistics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -94,7 +95,8 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgsH& a, const int block
 
     uint4 ra[2][NA], rb[2][NB];
     // loads the NEXT chunk in K order (chunks are requested strictly in order 0, 1, 2, ...) into register set `set`
-    auto load_stage = [&](int set) {
+    auto load_stage = [&](auto set_c) {
+        constexpr int set = decltype(set_c)::value;
         int t = kt, c = kc;
         if (UNIFORM) { t = __builtin_amdgcn_readfirstlane(t); c = __builtin_amdgcn_readfirstlane(c); }
         const bool kok = t < ntaps;
@@ -119,7 +121,8 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgsH& a, const int block
         kc += BKH;
         while (kc >= C) { kc -= C; ++kt; }
     };
-    auto to_lds = [&](int set, int buf) {
+    auto to_lds = [&](auto set_c, auto buf_c) {
+        constexpr int set = decltype(set_c)::value, buf = decltype(buf_c)::value;
         __bf16* As = smem_h + buf * STAGE;
         __bf16* Bs = As + BM_ * LDH;
 #pragma unroll
@@ -140,18 +143,21 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgsH& a, const int block
     const int koff = (lane >> 5) * 8;
 
     // prologue: chunks 0 and 1 requested; chunk 0 into LDS buffer 0, its registers re-loaded for chunk 2
-    load_stage(0);
-    if (nch > 1) load_stage(1);
-    to_lds(0, 0);
-    if (nch > 2) load_stage(0);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    load_stage(I0{});
+    if (nch > 1) load_stage(I1{});
+    to_lds(I0{}, I0{});
+    if (nch > 2) load_stage(I0{});
     __syncthreads();
-    for (int ch = 0; ch < nch; ++ch) {
-        const int cur = ch & 1;
+    // one K chunk; CUR (compile time: the register sets must not be indexed at run time) = parity of the chunk = its LDS buffer
+    auto step = [&](int ch, auto cur_c) {
+        constexpr int CUR = decltype(cur_c)::value;
         if (ch + 1 < nch) {                               // chunk ch + 1: registers -> the other buffer; then its registers take chunk ch + 3
-            to_lds(cur ^ 1, cur ^ 1);
-            if (ch + 3 < nch) load_stage(cur ^ 1);
+            to_lds(std::integral_constant<int, CUR ^ 1>{}, std::integral_constant<int, CUR ^ 1>{});
+            if (ch + 3 < nch) load_stage(std::integral_constant<int, CUR ^ 1>{});
         }
-        const __bf16* As = smem_h + cur * STAGE;
+        const __bf16* As = smem_h + CUR * STAGE;
         const __bf16* Bs = As + BM_ * LDH;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -165,7 +171,11 @@ __device__ __forceinline__ void igemm2_body(const IgemmArgsH& a, const int block
 #pragma unroll
                 for (int j = 0; j < NSUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();                                  // buffer cur^1 is complete, buffer cur is free
+        __syncthreads();                                  // buffer CUR^1 is complete, buffer CUR is free
+    };
+    for (int ch = 0; ch < nch; ch += 2) {
+        step(ch, std::integral_constant<int, 0>{});
+        if (ch + 1 < nch) step(ch + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue through LDS (as igemm_bf16.hip): acc[i][j] holds D[n = 32j + (r&3) + 8(r>>2) + 4h][pixel = 32i + (lane&31)]
@@ -287,18 +297,22 @@ int launch_t(const IgemmArgsH* a, int ncls, unsigned nwg, bool uniform, hipStrea
 }  // namespace
 
 // Pixel-tile height of the tap-table launch for an iteration grid of M pixels and N output channels, ncls launches sharing the
-// grid: 64-pixel tiles while 128-pixel ones would not give every CU three workgroups; 0 = the general kernel (igemm_bf16.hip).
+// grid; 0 = the general kernel (igemm_bf16.hip, 128-pixel tiles).  Measured at batch 32 (scripts/micro_igemm.py, round 3): below
+// one 128 x 128 workgroup per CU the 64-pixel tiles win (256 -> 256 @ 18 x 20: 47 -> 38 us, 512 -> 512 @ 9 x 10: 79 -> 51,
+// 256 -> 512 stride 2 @ 18 x 20: 44 -> 27); from 360 workgroups on (36 x 40 levels, 16 x 16 with 1024 channels) the general
+// kernel's five resident workgroups per CU beat two chunks in flight (35 against 46 us).
 int igemm_bf16_tile_m(long long M, int N, int ncls) {
     if (!unetrir_cfg().igemm2 || M <= 0 || M >= (1ll << 31)) return 0;
     const long long wg128 = ((M + 127) / 128) * ((N + 127) / 128) * ncls;
-    return wg128 < 3 * 256 ? 64 : 128;
+    return wg128 < 256 ? 64 : 0;
 }
 
 // a[0 .. ncls): 1 launch or the 4 output-parity classes of a stride-2 transposed layer (same shape, one grid)
 int launch_igemm2_fwd_bf16(const IgemmArgsH* a, int ncls, hipStream_t s) {
     const long long M = (long long)a[0].g.B * a[0].g.PH * a[0].g.PW;
     if (M <= 0 || a[0].g.N <= 0) return 0;
-    const int bm = igemm_bf16_tile_m(M, a[0].g.N, ncls);
+    int bm = igemm_bf16_tile_m(M, a[0].g.N, ncls);
+    if (bm == 0) bm = 128;
     const bool uniform = (a[0].g.C % BKH) == 0;
     const long long mt = (M + bm - 1) / bm;
     // channel tile: 128 when N > 64 and the 64-pixel x 128-channel tiles still fill the chip twice, else 64
