@@ -270,14 +270,17 @@ bool pw1x1_applies(const PwArgs& a) {
 }
 
 // channel tile and workgroup count of a launch: NT = 64 where N is a multiple of 64 and the input has at most 64 channels, else 32;
-// one workgroup = 4 waves x their strips of 32 pixels; the workgroup count per channel tile is a multiple of 8 (XCD mapping)
+// one workgroup = 4 waves x their strips of 32 pixels; the workgroup count per channel tile is a multiple of 8 (XCD mapping).
+// One or two workgroups per CU in total (measured, batch 32, scripts/micro_pw1x1.py: 32 -> 32 @ 128 x 128 with 512 / 2048 / 4096
+// workgroups: 15 / 26 / 45 us; 64 -> 64 @ 64 x 64 with 256 / 1024: 14 / 29 us): every workgroup pays for its kernel tile, its bias
+// and its row of column statistics, a wave keeps its strips in flight by itself.
 static void pw1x1_plan(const PwArgs& a, int* nb, unsigned* per_tile) {
     *nb = (a.N % 64 == 0 && a.C <= 64) ? 2 : 1;
     const int ntN = a.N / (32 * *nb);
     const long long M = (long long)a.B * a.PH * a.PW;
     const long long groups = (M + 127) / 128;              // 4 strips
-    long long g = 2048 / ntN;
-    if (g < 64) g = 64;
+    long long g = ((*nb == 1 && a.C <= 32) ? 512 : 256) / ntN;
+    if (g < 8) g = 8;
     if (g > groups) g = groups;
     g = (g + 7) / 8 * 8;
     *per_tile = (unsigned)g;
