@@ -8,11 +8,13 @@ definition of the operators.
                      every rounding step);
   * shift / batch    a 'same' convolution commutes with an image shift away from the border and treats every image of the
                      batch alone, bit-exactly: exposes any tile-seam or halo mistake at the real tile counts;
-  * cross-kernel     128 output channels in one launch (conv3x3g) == two 64-channel launches (conv3x3h) to bf16 rounding;
+  * cross-kernel     128 output channels in one launch (conv3x3p / conv3x3g) == two 64-channel launches (conv3x3g's 64-channel
+                     tiles since round 2; conv3x3h before) to bf16 rounding;
   * whole step       determinism, sigmoid range, BatchNorm output statistics (mean 0, variance 1 per channel), loss
                      invariance under a permutation of the batch, finite decreasing loss.
-The layers are the ones the step actually runs: 64->64 @ 256^2 (conv3x3h), 128->128 @ 128^2 (conv3x3g), the stride-2
-64->128 @ 256^2 -> 128^2 (igemm forward, upconv3x3 data gradient, stride-2 weight gradient) and the transposed 128->64.
+The layers are the ones the step actually runs: 64->64 @ 256^2 (conv3x3s), 128->128 @ 128^2 (conv3x3p), the stride-2
+64->128 @ 256^2 -> 128^2 (conv3x3d forward, upconv3x3q data gradient, wgrad3x3d) and the transposed 128->64; the last test holds the
+bf16 engine against the fp32 engine at this size (gradient fidelity of the benchmarked mode).
 """
 import math
 

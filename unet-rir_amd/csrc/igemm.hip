@@ -616,6 +616,7 @@ __global__ __launch_bounds__(512) void splitk_reduce_wide_kernel(const float* __
 
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s) {
     const size_t n4 = (n + 3) / 4;
+    // (round 3: taking larger outputs too - up to 4096 narrow workgroups - moves single launches by +-8 us and the step by nothing)
     if ((n & 3) == 0 && nsplit >= 32 && (n4 + 63) / 64 < 128 && (((uintptr_t)part | (uintptr_t)out | (uintptr_t)w) & 15) == 0) {
         hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(512), 0, s, part, nsplit, n, out, reg, w);
         return (int)hipGetLastError();
