@@ -79,10 +79,11 @@ int unetrir_abi_version(void);
  *        upconv3x3q     UNETRIR_UPCONV3X3Q     bf16 persistent form of upconv3x3g for layers with >= 512 tiles (upconv3x3q.hip)
  *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup)
  *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip)
- *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip) */
+ *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip)
+ *        bn_fused       UNETRIR_BN_FUSED       its BatchNormalization passes of tensors <= 64 MB in one launch per direction (bnfused.hip: grid barriers) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2;
+        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2, bn_fused;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);
@@ -391,6 +392,17 @@ int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, 
                              float eps, float momentum, float* moving_mean, float* moving_var, float* affine, float* saved,
                              unetrir_stream_t stream);
 int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream);
+/* unetrir_bn_stats_colstat followed by unetrir_bn_act_add_* in one call: statistics rows -> affine / saved / moving statistics, then
+ * y = act(x * scale + shift (+ addend)).  Tensors of at most 64 MB run as ONE launch (the statistics are finished by the
+ * workgroups themselves, a grid barrier separates the two phases; the same holds for unetrir_bn_bwd_* / unetrir_bn_bwd_junction_*:
+ * reduce, finalize and apply in one launch); larger ones as the two launches. */
+int unetrir_bn_colstat_act_add_f32(const float* colstat, long long rows, const float* x, int ldx, long long P, int C, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
+                                   float* saved, int act, const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream);
+int unetrir_bn_colstat_act_add_bf16(const float* colstat, long long rows, const unetrir_bf16* x, int ldx, long long P, int C,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* moving_mean,
+                                    float* moving_var, float* affine, float* saved, int act, const unetrir_bf16* addend, int ldadd,
+                                    unetrir_bf16* y, int ldy, unetrir_stream_t stream);
 /* head data gradient on the matrix cores: dx[p][c] = sum_{n<2,kh,kw} dy[p - off][n] * w[n][kh][kw][c] (the adjoint of
  * unetrir_head6x6_fwd_bf16; w is the fp32 [>=2][6][6][C] kernel, rounded to bf16 on load).  Only channels 0,1 of dy are
  * read.  Supported for C a multiple of 32 up to 512 (unetrir_head6x6_dgrad_supported; 64 channels per workgroup, images wider

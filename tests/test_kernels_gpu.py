@@ -960,3 +960,62 @@ def test_small_problem_tap_table_kernel_equals_the_general_one(U, case):
         close(out[1]["cs"][:, 0], td.sum(dim=(0, 1, 2)), 2e-6, "colstat sum")
         close(out[1]["cs"][:, 1], (td * td).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares")
         assert out[1]["rows"] >= out[0]["rows"]                   # 64-pixel tiles: at least as many rows as the 128-pixel kernel
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(4, 16, 16, 64), (3, 9, 10, 24), (32, 32, 32, 128), (2, 7, 5, 8), (8, 64, 64, 32)])
+def test_fused_batchnorm_launches_equal_the_separate_ones(U, dtype, case):
+    """bnfused.hip: reduce / finalize / apply of BatchNormalization's backward pass (plain and junction form) and finalize / apply
+    of its forward pass in ONE launch each (grid barriers) against the separate launches (set_config(bn_fused=0)): same
+    arithmetic, partial sums grouped by other workgroup counts - equal to fp32 rounding of the fp64 sums; run-to-run bit-identical;
+    moving statistics, dgamma / dbeta, the skip operand's accumulated gradient included.  Channel counts that are not powers of two
+    take the un-hoisted loops."""
+    ops = U.ops
+    B, H, W, C = case
+    if dtype == "bf16" and C % 8:
+        pytest.skip("bf16 rows are 16 bytes")
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    gen = torch.Generator(device=DEV); gen.manual_seed(C * 7 + H)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(tdt)
+    P = B * H * W
+    x, da, skip = ops.Act(rnd(B, H, W, C)), ops.Act(rnd(B, H, W, C)), ops.Act(rnd(B, H, W, C))
+    gamma, beta = torch.rand(C, device=DEV, generator=gen) + 0.5, torch.rand(C, device=DEV, generator=gen) - 0.5
+    rows = 13
+    yd = x.base.double().view(P, C)
+    # column-statistics rows that add up to the tensor's sums (any split will do: 13 row blocks)
+    cst = torch.zeros((rows, C, 2), device=DEV)
+    for r in range(rows):
+        blk = yd[r * P // rows:(r + 1) * P // rows]
+        cst[r, :, 0] = blk.sum(0).float(); cst[r, :, 1] = (blk * blk).sum(0).float()
+    old = ops.get_config()
+    res = {}
+    try:
+        for on in (1, 0, 1):
+            ops.set_config(bn_fused=on)
+            ws = ops.Workspace(DEV)
+            aff, saved = torch.zeros(2 * C, device=DEV), torch.zeros(2 * C, device=DEV)
+            mm, mv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            y = ops.Act(torch.empty((B, H, W, C), dtype=tdt, device=DEV))
+            ops.bn_colstat_act_add(cst, rows, x, gamma, beta, aff, saved, y, 2, skip, mm, mv, 1e-3, 0.99)
+            dx, dxj = ops.Act(torch.empty((B, H, W, C), dtype=tdt, device=DEV)), ops.Act(torch.empty((B, H, W, C), dtype=tdt, device=DEV))
+            dg, db, dgj, dbj = (torch.empty(C, device=DEV) for _ in range(4))
+            ops.bn_bwd(da, x, None, aff, saved, dx, dg, db, ws, relu=2)
+            gs = ops.Act(skip.base.clone())
+            ops.bn_bwd_junction(da, x, y, aff, saved, dxj, dgj, dbj, ws, act=2, gskip=gs, gskip_add=gs)
+            torch.cuda.synchronize()
+            cur = dict(aff=aff.clone(), saved=saved.clone(), mm=mm.clone(), mv=mv.clone(), y=y.base.clone(), dx=dx.base.clone(), dg=dg.clone(),
+                       db=db.clone(), dxj=dxj.base.clone(), dgj=dgj.clone(), dbj=dbj.clone(), gs=gs.base.clone())
+            if on in res:
+                for k in cur:
+                    assert torch.equal(cur[k], res[on][k]), ("not reproducible", k)
+            res[on] = cur
+    finally:
+        ops.set_config(**old)
+    tol = 1e-5 if dtype == "f32" else 1e-2
+    for k in res[1]:
+        a, b = res[1][k].double(), res[0][k].double()
+        assert float((a - b).abs().max()) <= (1e-5 if k in ("aff", "saved", "mm", "mv", "dg", "db", "dgj", "dbj") else tol) * (float(b.abs().max()) + 1e-6), k
+    # and against the definition (fp64)
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    want = torch.nn.functional.leaky_relu((yd - mean) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double() + skip.base.double().view(P, C), 0.3)
+    assert float((res[1]["y"].double().view(P, C) - want).abs().max()) <= (1e-5 if dtype == "f32" else 2e-2) * float(want.abs().max())

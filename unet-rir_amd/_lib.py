@@ -22,7 +22,7 @@ class CastDesc(C.Structure):
 class Config(C.Structure):
     """unetrir_config: kernel-selection switches (include/unetrir.h)."""
     _fields_ = [(n, C.c_int) for n in ("conv3x3", "conv3x3g", "conv3x3g_pair", "conv3x3h", "conv3x3s", "conv3x3r", "stem",
-                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d", "conv3x3p", "upconv3x3q", "dyn_tiles", "pw1x1", "igemm2")]
+                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d", "conv3x3p", "upconv3x3q", "dyn_tiles", "pw1x1", "igemm2", "bn_fused")]
 
 
 class ConvGeom(C.Structure):
@@ -138,6 +138,8 @@ _SIGS = {
                                                             c_stream]),
     "unetrir_bn_stats_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float,
                                            c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "unetrir_bn_colstat_act_add_f32": (C.c_int, [c_f32p, C.c_longlong, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_stream]),
+    "unetrir_bn_colstat_act_add_bf16": (C.c_int, [c_f32p, C.c_longlong, c_f32p, C.c_int, C.c_longlong, C.c_int, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, c_stream]),
     "unetrir_colsum_colstat": (C.c_int, [c_f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, c_f32p, c_stream]),
     "unetrir_cast_weights_batched_bf16": (C.c_int, [C.c_void_p, C.c_int, c_stream]),
     "unetrir_dense_dgrad_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),

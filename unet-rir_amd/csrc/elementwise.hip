@@ -722,6 +722,11 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !chan_ok(da, ldda, P, C, VecOf<T>::N) || !dx || lddx < C || lddx % VecOf<T>::N || !affine || !saved || !ws ||
         ws_bytes < unetrir_bn_ws_bytes(P, C))
         return UNETRIR_EINVAL;
+    if (bn_fused_applies(P, C, (int)sizeof(T))) {        // small tensors: reduce, finalize and apply in one launch (bnfused.hip)
+        const int e = launch_bn_bwd_fused(sizeof(T) == 2, da, ldda, x, ldx, nullptr, 0, P, C, affine, saved, relu, dx, lddx, nullptr, 0, nullptr, 0,
+                                          dgamma, dbeta, ws, ws_bytes, s);
+        if (e != BN_FUSED_NOT_TAKEN) return e;
+    }
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
@@ -743,6 +748,11 @@ int bn_bwd_junction_impl(const T* da, int ldda, const T* x, int ldx, const T* ou
         !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C) || act < 0 || act > 2 || (gskip && (ldgs < C || ldgs % V)) ||
         (gskip_add && (!gskip || ldga < C || ldga % V)))
         return UNETRIR_EINVAL;
+    if (bn_fused_applies(P, C, (int)sizeof(T))) {
+        const int e = launch_bn_bwd_fused(sizeof(T) == 2, da, ldda, x, ldx, out, ldo, P, C, affine, saved, act, dx, lddx, gskip, ldgs, gskip_add,
+                                          ldga, dgamma, dbeta, ws, ws_bytes, s);
+        if (e != BN_FUSED_NOT_TAKEN) return e;
+    }
     const ChanPlan pl = chan_plan(P, C, V);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
@@ -794,7 +804,9 @@ extern "C" {
 size_t unetrir_bn_ws_bytes(long long P, int C) {
     if (P <= 0 || C <= 0) return 0;
     const ChanPlan pl = chan_plan(P, C);
-    return ((size_t)pl.nslab * C * 2) * sizeof(double) + (size_t)2 * C * sizeof(float);
+    size_t b = ((size_t)pl.nslab * C * 2) * sizeof(double) + (size_t)2 * C * sizeof(float);
+    if (bn_fused_applies(P, C, 2) || bn_fused_applies(P, C, 4)) { const size_t f = bn_fused_ws_bytes(C); if (f > b) b = f; }
+    return b;
 }
 
 int unetrir_bn_stats_f32(const float* x, int ldx, long long P, int C, const float* gamma, const float* beta, float eps,
@@ -1108,6 +1120,26 @@ int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetr
 
 }  // extern "C"
 
+/* BatchNormalization forward from a convolution's column statistics in ONE call: statistics -> affine (+ moving statistics), then
+ * y = act(x * scale + shift (+ addend)); small tensors in one launch (bnfused.hip), else the finalize and the apply launch. */
+template <typename T>
+static int bn_colstat_act_add_impl(const float* colstat, long long rows, const T* x, int ldx, long long P, int C, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* mm, float* mv, float* affine, float* saved, int act,
+                                   const T* addend, int ldadd, T* y, int ldy, hipStream_t s) {
+    constexpr int V = VecOf<T>::N;
+    if (!colstat || rows <= 0 || rows > 0x7fffffffLL || !chan_ok(x, ldx, P, C, V) || !affine || !saved || !y || ldy < C || ldy % V || act < 0 ||
+        act > 2 || (addend && (ldadd < C || ldadd % V)))
+        return UNETRIR_EINVAL;
+    if (bn_fused_applies(P, C, (int)sizeof(T))) {
+        const int e = launch_bn_fwd_fused(sizeof(T) == 2, colstat, rows, x, ldx, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved, act, addend,
+                                          ldadd, y, ldy, s);
+        if (e != BN_FUSED_NOT_TAKEN) return e;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(256), 0, s, colstat, (int)rows, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, x, ldx, P, C, (const float*)affine, act, y, ldy, addend, ldadd);
+    return (int)hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------------
 // statistics from the per-tile partials a convolution epilogue produced (unetrir_conv2d_*_colstat_bf16):
 // colstat is [rows][ldc][2] floats (sum, sum of squares); fixed-order fp64 reduction over the rows
@@ -1121,6 +1153,21 @@ int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, 
     hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, colstat, (int)rows, P, C, gamma, beta, eps,
                        momentum, moving_mean, moving_var, affine, saved);
     return (int)hipGetLastError();
+}
+
+int unetrir_bn_colstat_act_add_f32(const float* colstat, long long rows, const float* x, int ldx, long long P, int C, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
+                                   float* saved, int act, const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream) {
+    return bn_colstat_act_add_impl<float>(colstat, rows, x, ldx, P, C, gamma, beta, eps, momentum, moving_mean, moving_var, affine, saved, act,
+                                          addend, ldadd, y, ldy, (hipStream_t)stream);
+}
+
+int unetrir_bn_colstat_act_add_bf16(const float* colstat, long long rows, const unetrir_bf16* x, int ldx, long long P, int C, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
+                                    float* saved, int act, const unetrir_bf16* addend, int ldadd, unetrir_bf16* y, int ldy,
+                                    unetrir_stream_t stream) {
+    return bn_colstat_act_add_impl<__bf16>(colstat, rows, (const __bf16*)x, ldx, P, C, gamma, beta, eps, momentum, moving_mean, moving_var, affine,
+                                           saved, act, (const __bf16*)addend, ldadd, (__bf16*)y, ldy, (hipStream_t)stream);
 }
 
 int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream) {

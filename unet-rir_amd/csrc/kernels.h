@@ -165,6 +165,19 @@ unsigned* sched_slot(hipStream_t s);
 #define UNETRIR_SYNC_TILES 512
 #define UNETRIR_SYNC_WORDS 520
 unsigned* sync_slot(hipStream_t s);
+
+// BatchNormalization passes of small tensors in one launch per direction (bnfused.hip): words UNETRIR_SYNC_TILES .. + 3 of the sync
+// slot are the two grid-barrier counters (+ their give-up flags).  BN_FUSED_NOT_TAKEN: no slot / no occupancy answer / workspace
+// too small - the caller runs the separate launches.
+#define BN_FUSED_NOT_TAKEN (-12346)
+bool bn_fused_applies(long long P, int C, int elem_bytes);
+size_t bn_fused_ws_bytes(int C);
+int launch_bn_bwd_fused(int bf16, const void* da, int ldda, const void* x, int ldx, const void* msk, int ldm, long long P, int C,
+                        const float* affine, const float* saved, int act, void* dx, int lddx, void* g2, int ldg2, const void* g2add,
+                        int ldg2a, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t s);
+int launch_bn_fwd_fused(int bf16, const float* colstat, long long rows, const void* x, int ldx, long long P, int C, const float* gamma,
+                        const float* beta, float eps, float momentum, float* mm, float* mv, float* affine, float* saved, int act,
+                        const void* addend, int ldadd, void* y, int ldy, hipStream_t s);
 bool conv3x3p_applies(const Conv3Args& a);          // conv3x3g's layers with >= 512 tiles: persistent form, continuous K loop across tiles
 long long conv3x3p_colstat_rows(const Conv3Args& a);
 int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s);

@@ -664,9 +664,9 @@ class UNetEngine(DeviceCounters):
             self._bn_relu_fwd(name, y, out)
             return
         ops.conv2d_fwd_colstat(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y, buf)
-        ops.bn_stats_colstat(buf, rows, y.P, y.C, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name],
-                             self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
-        ops.bn_apply(y, self.bn_affine[name], out, relu=True)
+        # statistics rows -> affine / moving statistics -> BatchNorm + ReLU: one call (small tensors: one launch, bnfused.hip)
+        ops.bn_colstat_act_add(buf, rows, y, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name], out, 1, None,
+                               self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
 
     def _dgrad_colsum(self, name, dy: Act, dx: Act, bias_grad, c0, c_n):
         """Data gradient of conv `name` plus the bias gradient of the layer that produced its input (channels

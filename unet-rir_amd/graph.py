@@ -288,9 +288,10 @@ class GraphEngine(DeviceCounters):
         gj = Act(torch.empty_like(x.a.base)) if (addend is not None and not (batchnorm and self.fused_junction)) else None
 
         def fwd():
-            if batchnorm and self.training and x.cst is not None:
-                ops.bn_stats_colstat(x.cst[1], x.cst[0], x.a.P, c, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, mm, mv,
-                                     BN_EPS, BN_MOMENTUM)
+            if batchnorm and self.training and x.cst is not None:      # statistics rows -> affine -> apply (+ Add, activation): one call
+                ops.bn_colstat_act_add(x.cst[1], x.cst[0], x.a, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, y.a, act,
+                                       addend.a if addend is not None else None, mm, mv, BN_EPS, BN_MOMENTUM)
+                return
             elif batchnorm and self.training:
                 ops.bn_stats(x.a, self._p[name + ".gamma"], self._p[name + ".beta"], aff, saved, self.ws, mm, mv, BN_EPS, BN_MOMENTUM)
             elif batchnorm:          # training=False: normalise with the moving statistics

@@ -159,6 +159,14 @@ def bn_stats_colstat(colstat, rows, P, C_, gamma, beta, affine, saved, moving_me
                                               _p(moving_var), _p(affine), _p(saved), _stream()), "bn_stats_colstat")
 
 
+def bn_colstat_act_add(colstat, rows, x: Act, gamma, beta, affine, saved, y: Act, act=2, addend: Act = None, moving_mean=None,
+                       moving_var=None, eps=1e-3, momentum=0.99):
+    """BatchNormalization (training) from fused conv-epilogue partials + Add + activation in one call (tensors <= 64 MB: one launch)."""
+    check(_fn("bn_colstat_act_add", x.sfx)(_p(colstat), rows, _p(x), x.ld, x.P, x.C, _p(gamma), _p(beta), eps, momentum, _p(moving_mean),
+                                            _p(moving_var), _p(affine), _p(saved), int(act), _p(addend),
+                                            addend.ld if addend is not None else 0, _p(y), y.ld, _stream()), "bn_colstat_act_add")
+
+
 def colsum_colstat(colstat, rows, ldc, c0, C_, out):
     """Bias gradient from fused conv-epilogue partials: out[c] = sum over rows of colstat[row][c0 + c][0]."""
     check(_lib.lib().unetrir_colsum_colstat(_p(colstat), rows, ldc, c0, C_, _p(out), _stream()), "colsum_colstat")
