@@ -60,7 +60,7 @@ int unetrir_abi_version(void);
  *      the next more general one - for A/B measurements and for parity cross-checks between kernels.  The switches are
  *      read ONCE, at first use, from the environment variables named below (the only variables the library reads) into
  *      this struct; unetrir_set_config replaces the values in effect (tests, A/B scripts: process-global, not
- *      thread-safe - call it while no launch is being issued).  Defaults: all 1.
+ *      thread-safe - call it while no launch is being issued).  Defaults: all 1 except bn_fused.
  *        conv3x3        UNETRIR_CONV3X3        3x3 stride-1: patch-staged kernels at all (0: tap-table implicit GEMM)
  *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels, and 64 output channels from > 64 input channels (64-channel tiles; conv3x3g.hip)
  *        conv3x3g_pair  UNETRIR_CONV3X3G_PAIR  its two-images-per-tile form for images <= 16 wide: 0 off, 1 when it yields
@@ -80,7 +80,8 @@ int unetrir_abi_version(void);
  *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup)
  *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip)
  *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip)
- *        bn_fused       UNETRIR_BN_FUSED       its BatchNormalization passes of tensors <= 64 MB in one launch per direction (bnfused.hip: grid barriers) */
+ *        bn_fused       UNETRIR_BN_FUSED       its BatchNormalization passes of tensors <= 64 MB in one launch per direction (bnfused.hip: grid
+ *                                              barriers).  DEFAULT 0: measured slower than the separate launches on MI355X (the numbers are in the file) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
         wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2, bn_fused;
@@ -393,9 +394,9 @@ int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, 
                              unetrir_stream_t stream);
 int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream);
 /* unetrir_bn_stats_colstat followed by unetrir_bn_act_add_* in one call: statistics rows -> affine / saved / moving statistics, then
- * y = act(x * scale + shift (+ addend)).  Tensors of at most 64 MB run as ONE launch (the statistics are finished by the
- * workgroups themselves, a grid barrier separates the two phases; the same holds for unetrir_bn_bwd_* / unetrir_bn_bwd_junction_*:
- * reduce, finalize and apply in one launch); larger ones as the two launches. */
+ * y = act(x * scale + shift (+ addend)): the finalize and the apply launch.  With the switch bn_fused = 1 tensors of at most 64 MB
+ * run as ONE launch (the statistics are finished by the workgroups themselves, a grid barrier separates the phases; likewise
+ * unetrir_bn_bwd_* / unetrir_bn_bwd_junction_*: reduce, finalize, apply in one launch) - measured slower, off by default. */
 int unetrir_bn_colstat_act_add_f32(const float* colstat, long long rows, const float* x, int ldx, long long P, int C, const float* gamma,
                                    const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
                                    float* saved, int act, const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream);

@@ -8,6 +8,9 @@ import unet_rir_amd as U
 if "--lib" in sys.argv:      # another build of the library (A/B of two builds, one process each)
     U._lib.use_library(os.path.abspath(sys.argv[sys.argv.index("--lib") + 1]))
 ops = U.ops
+for a_ in [v for v in sys.argv[1:] if v.startswith("--") and "=" in v]:       # --bn_fused=0: kernel-selection switches
+    k_, v_ = a_[2:].split("=")
+    ops.set_config(**{k_: int(v_)})
 dev = "cuda:0"
 B = 32
 ws = ops.Workspace(dev)
@@ -36,5 +39,8 @@ for HW, C in SHAPES:
     t_b = timeit(lambda: ops.bn_bwd(da, x, gamma, affine, saved, dx, dg, db, ws))
     t_c = timeit(lambda: ops.colsum(x, db, ws))
     t_a = timeit(lambda: ops.bn_apply(x, affine, dx, relu=True))
+    rows = 256
+    cst = torch.rand((rows, C, 2), device=dev)
+    t_f = timeit(lambda: ops.bn_colstat_act_add(cst, rows, x, gamma, beta, affine, saved, dx, 2, None))
     print(f"sweep={os.environ.get('UNETRIR_CHAN_SWEEP','1')} {HW}x{HW}x{C}: bn_stats {t_s:.1f} us ({nbytes/t_s/1e6:.2f} TB/s)  "
-          f"bn_bwd {t_b:.1f} us ({5*nbytes/t_b/1e6:.2f} TB/s over 5 passes)  colsum {t_c:.1f} us ({nbytes/t_c/1e6:.2f} TB/s)  bn_apply {t_a:.1f} us ({2*nbytes/t_a/1e6:.2f} TB/s) nt={os.environ.get('UNETRIR_BN_NT','0')}")
+          f"bn_bwd {t_b:.1f} us ({5*nbytes/t_b/1e6:.2f} TB/s over 5 passes)  colsum {t_c:.1f} us ({nbytes/t_c/1e6:.2f} TB/s)  bn_apply {t_a:.1f} us ({2*nbytes/t_a/1e6:.2f} TB/s)  colstat->apply {t_f:.1f} us nt={os.environ.get('UNETRIR_BN_NT','0')}")

@@ -13,11 +13,19 @@
 //   forward   (1) workgroup c reduces channel c of the convolution epilogue's column-statistics rows -> scale / shift, saved mean /
 //             rstd, moving statistics | barrier | (2) y = act(x * scale + shift (+ addend)).
 //
-// The barrier is an arrival counter in the stream's sync slot (kernels.h): every workgroup releases its writes (agent-scope fence),
-// increments the counter and thread 0 polls it; the count of workgroups is capped by what the device can hold at once (occupancy
-// query), a workgroup that cannot be placed yet is simply late - nothing it waits for depends on it - and the poll gives up after
-// ~2^22 rounds (a flag in the slot) instead of hanging the device.  Same arithmetic and summation orders as the separate launches:
-// results are bit-reproducible run to run (the partial rows are indexed by workgroup, not by arrival).
+// The barrier is an arrival counter in the stream's sync slot (kernels.h): a workgroup increments it once its stores are
+// acknowledged and thread 0 polls it; one workgroup per CU (all resident at once on an idle device; a workgroup that cannot be
+// placed yet is simply late - nothing it waits for depends on it) and the poll gives up after ~2^22 rounds (a flag in the slot)
+// instead of hanging the device.  Same arithmetic as the separate launches, partial rows indexed by workgroup (not by arrival):
+// bit-reproducible run to run.
+//
+// MEASURED AND NOT ADOPTED (round 3, scripts/micro_bn.py --resae --bn_fused=0|1, batch 32): OFF by default (switch bn_fused).
+//   backward, separate launches / fused:  128 x 128 x 32: 48 / 69 us   64 x 64 x 64: 30 / 46   32 x 32 x 128: 19 / 32   16 x 16 x 256: 17 / 28
+//   forward (finalize + apply) / fused:                   16 / 26                    12 / 17                    13 / 16                    13 / 14
+// A software grid barrier costs ~8 us at 256 workgroups (256 pollers of one memory-side counter; with agent-scope fences instead of
+// write-through stores 25 us, and 80 us at 1024 workgroups), i.e. MORE than the kernel boundary it replaces (~3 us), and 256
+// workgroups of 4 waves do not keep enough loads in flight for the streaming phases (the separate kernels run 1024-4096).  On this
+// device a kernel boundary is the cheaper grid-wide synchronisation; kept as a tested switch so that the measurement can be repeated.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -46,20 +54,29 @@ __device__ __forceinline__ void stvec(__bf16* p, const float (&o)[8]) {
     *reinterpret_cast<bfx8*>(p) = v;
 }
 
-// all threads of every workgroup of the launch call this; `target` = workgroups x (number of this barrier, 1-based)
+// Values that cross workgroups inside a launch (the partial sums, the finished per-channel constants) are written and read with
+// agent-scope atomic stores / loads: write-through stores (sc1) and cache-bypassing loads, coherent at the memory side of the 8
+// XCDs' L2s WITHOUT cache-wide fences.  (A release / acquire fence pair per workgroup - buffer_wbl2 walks the whole L2 - cost
+// 25 us per barrier at 256 workgroups and 80 us at 1024.)
+__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all threads of every workgroup of the launch call this; `target` = workgroups x (number of this barrier, 1-based).
+// __syncthreads() = every wave's stores are acknowledged (s_waitcnt vmcnt(0): for the write-through stores above that is "visible
+// device-wide"); then one arrival per workgroup and thread 0 polls.
 __device__ __forceinline__ void grid_barrier(unsigned* ctr, unsigned target) {
-    __threadfence();                                   // release: this wave's stores are written back (agent scope)
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(32);
             if (++spins > (1u << 22)) { __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // give up, leave a mark
         }
     }
     __syncthreads();
-    __threadfence();                                   // acquire: drop stale lines before reading the others' results
 }
 // the last workgroup to finish leaves the counter at zero for the next launch on this stream
 __device__ __forceinline__ void grid_finish(unsigned* ctr, unsigned total_after) {
@@ -72,10 +89,13 @@ __device__ __forceinline__ void grid_finish(unsigned* ctr, unsigned total_after)
 
 // fixed-order sum of `n` partial (a, b) pairs of channel c by the 256 threads of a workgroup: thread k takes rows k, k + 256, ...,
 // then a tree over the 256 thread sums (the order of elementwise.hip's slab_sum)
-template <typename PT>
+template <typename PT, bool DEV>
 __device__ __forceinline__ void rows_sum(const PT* part, int n, int C, int c, double* red, double& s, double& ss) {
     double a = 0, b = 0;
-    for (int k = threadIdx.x; k < n; k += 256) { a += (double)part[((size_t)k * C + c) * 2]; b += (double)part[((size_t)k * C + c) * 2 + 1]; }
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const PT* q = part + ((size_t)k * C + c) * 2;
+        a += (double)(DEV ? ld_dev(q) : q[0]); b += (double)(DEV ? ld_dev(q + 1) : q[1]);
+    }
     __syncthreads();
     red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
     __syncthreads();
@@ -151,8 +171,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__
         if (rl == 0 && cok) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
-                part[((size_t)blockIdx.x * C + c0 + k) * 2 + 0] = s0[k];
-                part[((size_t)blockIdx.x * C + c0 + k) * 2 + 1] = s1[k];
+                st_dev(part + ((size_t)blockIdx.x * C + c0 + k) * 2 + 0, s0[k]);
+                st_dev(part + ((size_t)blockIdx.x * C + c0 + k) * 2 + 1, s1[k]);
             }
         }
     }
@@ -161,12 +181,12 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__
     // ---- phase 2: workgroup b finishes channels b, b + G, ...
     for (int c = blockIdx.x; c < C; c += G) {
         double s, ss;
-        rows_sum<double>(part, G, C, c, red, s, ss);
+        rows_sum<double, true>(part, G, C, c, red, s, ss);
         if (tid == 0) {
             if (dbeta) dbeta[c] = (float)s;
             if (dgamma) dgamma[c] = (float)ss;
-            coef[c] = (float)(s / (double)P);
-            coef[C + c] = (float)(ss / (double)P);
+            st_dev(coef + c, (float)(s / (double)P));
+            st_dev(coef + C + c, (float)(ss / (double)P));
         }
     }
     grid_barrier(sync, 2u * (unsigned)G);
@@ -181,13 +201,17 @@ __global__ __launch_bounds__(256) void bn_bwd_fused_kernel(const T* __restrict__
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             sc[k] = affine[cc + k]; sh[k] = affine[C + cc + k]; mu[k] = saved[cc + k]; rs[k] = saved[C + cc + k];
-            c1[k] = coef[cc + k]; c2[k] = coef[C + cc + k];
+            c1[k] = ld_dev(coef + cc + k); c2[k] = ld_dev(coef + C + cc + k);
         }
     };
-    if (hoist) consts((int)(((long long)blockIdx.x * 256 + tid) % CQ) * V);
-    for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += stride) {
-        const long long p = i / CQ;
-        const int cc = (int)(i - p * CQ) * V;
+    const long long i0 = (long long)blockIdx.x * 256 + tid;
+    if (hoist) consts((int)(i0 % CQ) * V);
+    const long long pstep = stride / CQ;               // hoisted form: the pixel index advances by a constant, no division in the loop
+    long long ph = i0 / CQ;
+    const int cch = (int)(i0 % CQ) * V;
+    for (long long i = i0; i < total; i += stride, ph += pstep) {
+        const long long p = hoist ? ph : i / CQ;
+        const int cc = hoist ? cch : (int)(i - p * CQ) * V;
         if (!hoist) consts(cc);
         float xv[V], gv[V], mv[V], out[V], go[V];
         ldvec(x + (size_t)p * ldx + cc, xv);
@@ -227,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* colstat,
     const int tid = threadIdx.x, G = gridDim.x;
     for (int c = blockIdx.x; c < C; c += G) {          // the arithmetic of bn_finalize_kernel (elementwise.hip)
         double s, ss;
-        rows_sum<float>(colstat, rows, C, c, red, s, ss);
+        rows_sum<float, false>(colstat, rows, C, c, red, s, ss);      // written by an earlier launch: ordinary loads
         if (tid == 0) {
             const double mean = s / (double)P;
             double var = ss / (double)P - mean * mean;
@@ -235,8 +259,8 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* colstat,
             const float rstd = (float)(1.0 / sqrt(var + (double)eps));
             const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
             const float scale = g * rstd;
-            affine[c] = scale;
-            affine[C + c] = b - (float)mean * scale;
+            st_dev(affine + c, scale);
+            st_dev(affine + C + c, b - (float)mean * scale);
             saved[c] = (float)mean;
             saved[C + c] = rstd;
             if (moving_mean) moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)mean;
@@ -254,12 +278,16 @@ __global__ __launch_bounds__(256) void bn_fwd_fused_kernel(const float* colstat,
     float sc[V], sh[V];
     auto consts = [&](int cc) {
 #pragma unroll
-        for (int k = 0; k < V; ++k) { sc[k] = affine[cc + k]; sh[k] = affine[C + cc + k]; }
+        for (int k = 0; k < V; ++k) { sc[k] = ld_dev(affine + cc + k); sh[k] = ld_dev(affine + C + cc + k); }
     };
-    if (hoist) consts((int)(((long long)blockIdx.x * 256 + tid) % CQ) * V);
-    for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += stride) {
-        const long long p = i / CQ;
-        const int cc = (int)(i - p * CQ) * V;
+    const long long i0 = (long long)blockIdx.x * 256 + tid;
+    if (hoist) consts((int)(i0 % CQ) * V);
+    const long long pstep = stride / CQ;
+    long long ph = i0 / CQ;
+    const int cch = (int)(i0 % CQ) * V;
+    for (long long i = i0; i < total; i += stride, ph += pstep) {
+        const long long p = hoist ? ph : i / CQ;
+        const int cc = hoist ? cch : (int)(i - p * CQ) * V;
         if (!hoist) consts(cc);
         float r[V];
         ldvec(x + (size_t)p * ldx + cc, r);
@@ -287,8 +315,8 @@ int resident_cap(K kernel) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) return 0;
-    long long cap = (long long)cus * (per_cu > 4 ? 4 : per_cu);
-    return cap > 1024 ? 1024 : (int)cap;
+    (void)per_cu;                  // one workgroup per CU: every additional resident workgroup is another poller of the arrival counter
+    return cus > 1024 ? 1024 : cus;
 }
 
 }  // namespace
