@@ -29,6 +29,9 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+_DEFAULT_OFF = ("bn_fused",)      # include/unetrir.h: every switch defaults to 1 except these
+
+
 @pytest.fixture(autouse=True)
 def _restore_kernel_switches():
     """Tests may flip kernel-selection switches (ops.set_config); every test starts from and returns to the defaults."""
@@ -36,6 +39,6 @@ def _restore_kernel_switches():
     try:
         import unet_rir_amd
         if unet_rir_amd._lib._LIB is not None:
-            unet_rir_amd.ops.set_config(**{n: 1 for n, _ in unet_rir_amd._lib.Config._fields_})
+            unet_rir_amd.ops.set_config(**{n: (0 if n in _DEFAULT_OFF else 1) for n, _ in unet_rir_amd._lib.Config._fields_})
     except Exception:
         pass
