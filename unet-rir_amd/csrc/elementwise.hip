@@ -170,36 +170,50 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
     }
 }
 
-// Block-wide (256 threads, one block per channel) fixed-order sum of the per-slab partials of channel c.
+// Fixed-order sum of the per-slab partials of FIN_CH consecutive channels by one block of FIN_T threads: thread (lane, ch) adds
+// slabs lane, lane + FIN_T/FIN_CH, ... of channel c0 + ch (the FIN_CH threads of a lane read one contiguous 64- or 128-byte run of
+// a slab row: with one block per channel every 16-byte pair came from a line of its own, 10 us per launch at 2048 slabs), then a
+// tree over the lanes in a fixed pairing order.  Every thread returns the sums of ITS channel (c0 + (threadIdx.x % FIN_CH)).
+constexpr int FIN_CH = 8, FIN_T = 1024, FIN_L = FIN_T / FIN_CH;
+template <typename PT> struct Pair2;
+template <> struct Pair2<double> { using type = double2; };
+template <> struct Pair2<float> { using type = float2; };
 template <typename PT>
-__device__ __forceinline__ void slab_sum(const PT* __restrict__ part, int nslab, int C, int c, double& s, double& ss) {
-    __shared__ double red[256 * 2];
+__device__ __forceinline__ void slab_sum(const PT* __restrict__ part, int nslab, int C, int c0, double& s, double& ss, int cend = 0x7fffffff) {
+    __shared__ double red[FIN_T * 2];
+    using P2 = typename Pair2<PT>::type;
+    const int ch = threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH, c = c0 + ch;
     double a = 0, b = 0;
-#pragma unroll 4
-    for (int k = threadIdx.x; k < nslab; k += 256) { a += (double)part[((size_t)k * C + c) * 2]; b += (double)part[((size_t)k * C + c) * 2 + 1]; }
+    if (c < C && c < cend) {          // C: channels per slab row (the row stride); cend: end of the range asked for
+#pragma unroll 8
+        for (int k = ln; k < nslab; k += FIN_L) {
+            const P2 v = *reinterpret_cast<const P2*>(part + ((size_t)k * C + c) * 2);
+            a += (double)v.x; b += (double)v.y;
+        }
+    }
     red[threadIdx.x * 2] = a; red[threadIdx.x * 2 + 1] = b;
     __syncthreads();
-    // tree over the 256 partial sums in a fixed pairing order
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) {
-            red[threadIdx.x * 2] += red[(threadIdx.x + st) * 2];
-            red[threadIdx.x * 2 + 1] += red[(threadIdx.x + st) * 2 + 1];
+    for (int st = FIN_L / 2; st > 0; st >>= 1) {
+        if (ln < st) {
+            red[threadIdx.x * 2] += red[(threadIdx.x + st * FIN_CH) * 2];
+            red[threadIdx.x * 2 + 1] += red[(threadIdx.x + st * FIN_CH) * 2 + 1];
         }
         __syncthreads();
     }
-    s = red[0]; ss = red[1];
+    s = red[ch * 2]; ss = red[ch * 2 + 1];
 }
+inline dim3 fin_grid(int C) { return dim3((C + FIN_CH - 1) / FIN_CH); }
 
 // stage 2 (BN statistics): mean / biased variance -> affine, saved, moving statistics
 template <typename PT>
-__global__ void bn_finalize_kernel(const PT* __restrict__ part, int nslab, long long P, int C,
+__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(const PT* __restrict__ part, int nslab, long long P, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                    float* __restrict__ affine, float* __restrict__ saved) {
-    const int c = blockIdx.x;
+    const int c = blockIdx.x * FIN_CH + threadIdx.x;
     double s, ss;
-    slab_sum<PT>(part, nslab, C, c, s, ss);
-    if (threadIdx.x != 0) return;
+    slab_sum<PT>(part, nslab, C, blockIdx.x * FIN_CH, s, ss);
+    if (threadIdx.x >= FIN_CH || c >= C) return;
     const double mean = s / (double)P;
     double var = ss / (double)P - mean * mean;
     if (var < 0) var = 0;
@@ -217,23 +231,24 @@ __global__ void bn_finalize_kernel(const PT* __restrict__ part, int nslab, long 
     }
 }
 
-// stage 2 (column sum): out[c] = sum_slabs
+// stage 2 (column sum): out[c] = sum_slabs of channel c0 + c, c < n
 template <typename PT>
-__global__ void colsum_finalize_kernel(const PT* __restrict__ part, int nslab, int C, float* __restrict__ out, int c0 = 0) {
-    const int c = blockIdx.x;
+__global__ __launch_bounds__(FIN_T) void colsum_finalize_kernel(const PT* __restrict__ part, int nslab, int C, float* __restrict__ out, int c0,
+                                                                int n) {
+    const int c = blockIdx.x * FIN_CH + threadIdx.x;
     double s, ss;
-    slab_sum<PT>(part, nslab, C, c0 + c, s, ss);
-    if (threadIdx.x == 0) out[c] = (float)s;
+    slab_sum<PT>(part, nslab, C, c0 + blockIdx.x * FIN_CH, s, ss, c0 + n);
+    if (threadIdx.x < FIN_CH && c < n) out[c] = (float)s;
 }
 
 // stage 2 (BN backward): dgamma, dbeta and the two means the dx pass needs -> coef[2*C]
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
+__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(const double* __restrict__ part, int nslab, long long P, int C,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef) {
-    const int c = blockIdx.x;
+    const int c = blockIdx.x * FIN_CH + threadIdx.x;
     double s, ss;
-    slab_sum(part, nslab, C, c, s, ss);
-    if (threadIdx.x != 0) return;
+    slab_sum(part, nslab, C, blockIdx.x * FIN_CH, s, ss);
+    if (threadIdx.x >= FIN_CH || c >= C) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)ss;
     coef[c] = (float)(s / (double)P);
@@ -704,7 +719,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, fin_grid(C), dim3(FIN_T), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
                        beta, eps, momentum, moving_mean, moving_var, affine, saved);
     return (int)hipGetLastError();
 }
@@ -732,7 +747,7 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
     hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, da, ldda, affine, saved,
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, fin_grid(C), dim3(FIN_T), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, relu | bn_nohoist_flag(), dx, lddx);
     return (int)hipGetLastError();
@@ -758,7 +773,7 @@ int bn_bwd_junction_impl(const T* da, int ldda, const T* x, int ldx, const T* ou
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
     hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, da, ldda, affine, saved,
                        act, P, C, pl.QB, pl.rows_per_slab, part, out, ldo);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, fin_grid(C), dim3(FIN_T), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, act, dx, lddx, out, ldo, gskip, ldgs, gskip_add, ldga);
     return (int)hipGetLastError();
@@ -770,7 +785,7 @@ int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, s
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel<double>, dim3(C), dim3(256), 0, s, (const double*)ws, pl.nslab, C, out, 0);
+    hipLaunchKernelGGL(colsum_finalize_kernel<double>, fin_grid(C), dim3(FIN_T), 0, s, (const double*)ws, pl.nslab, C, out, 0, C);
     return (int)hipGetLastError();
 }
 
@@ -1135,7 +1150,7 @@ static int bn_colstat_act_add_impl(const float* colstat, long long rows, const T
                                           ldadd, y, ldy, s);
         if (e != BN_FUSED_NOT_TAKEN) return e;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(256), 0, s, colstat, (int)rows, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved);
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, fin_grid(C), dim3(FIN_T), 0, s, colstat, (int)rows, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved);
     hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, x, ldx, P, C, (const float*)affine, act, y, ldy, addend, ldadd);
     return (int)hipGetLastError();
 }
@@ -1150,7 +1165,7 @@ int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, 
                              float momentum, float* moving_mean, float* moving_var, float* affine, float* saved,
                              unetrir_stream_t stream) {
     if (!colstat || rows <= 0 || rows > 0x7fffffffLL || P <= 0 || C <= 0 || !affine || !saved) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, colstat, (int)rows, P, C, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, fin_grid(C), dim3(FIN_T), 0, (hipStream_t)stream, colstat, (int)rows, P, C, gamma, beta, eps,
                        momentum, moving_mean, moving_var, affine, saved);
     return (int)hipGetLastError();
 }
@@ -1172,7 +1187,7 @@ int unetrir_bn_colstat_act_add_bf16(const float* colstat, long long rows, const 
 
 int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream) {
     if (!colstat || rows <= 0 || rows > 0x7fffffffLL || C <= 0 || c0 < 0 || c0 + C > ldc || !out) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(colsum_finalize_kernel<float>, dim3(C), dim3(256), 0, (hipStream_t)stream, colstat, (int)rows, ldc, out, c0);
+    hipLaunchKernelGGL(colsum_finalize_kernel<float>, fin_grid(C), dim3(FIN_T), 0, (hipStream_t)stream, colstat, (int)rows, ldc, out, c0, C);
     return (int)hipGetLastError();
 }
 
