@@ -81,10 +81,11 @@ int unetrir_abi_version(void);
  *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip)
  *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip)
  *        bn_fused       UNETRIR_BN_FUSED       its BatchNormalization passes of tensors <= 64 MB in one launch per direction (bnfused.hip: grid
- *                                              barriers).  DEFAULT 0: measured slower than the separate launches on MI355X (the numbers are in the file) */
+ *                                              barriers).  DEFAULT 0: measured slower than the separate launches on MI355X (the numbers are in the file)
+ *        igemm3         UNETRIR_IGEMM3         bf16 tap-table kernel with LDS-DMA staged K chunks (C % 64 == 0, > 64 output channels: igemm3_bf16.hip) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2, bn_fused;
+        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2, bn_fused, igemm3;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);

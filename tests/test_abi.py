@@ -65,7 +65,7 @@ def test_library_reads_only_the_documented_environment_switches():
     found = sorted(set(re.findall(r"UNETRIR_[A-Z0-9_]+", out)))
     hdr = open(os.path.join(ROOT, "include", "unetrir.h")).read()
     documented = sorted(set(re.findall(r"(UNETRIR_[A-Z0-9_]+)\s+(?:3x3|bf16|its)", hdr)))
-    assert len(documented) == 19, documented
+    assert len(documented) == 20, documented
     assert found == documented, (found, documented)
     assert "unetrir_abl_set" not in out
     cfg = unet_rir_amd.ops.get_config()

@@ -914,6 +914,19 @@ def test_small_problem_tap_table_kernel_equals_the_general_one(U, case):
     dl_models/u_net.py:40-45) against the general tap-table kernel on the same layers: the same MFMA chain over the same K order,
     so identical bits - Conv2D forward (bias, addend, fused column statistics), data gradient, Conv2DTranspose forward and data
     gradient (stride 2: the four parity classes in one grid), odd sizes, channel counts that are not multiples of 64."""
+    _tap_table_ab(U, case, "igemm2", dict(igemm3=0))
+
+
+@pytest.mark.parametrize("case", [(4, 36, 40, 128, 128, 3, 1), (33, 36, 40, 128, 128, 3, 1), (3, 18, 20, 64, 200, 3, 1), (5, 9, 10, 256, 128, 3, 1),
+                                  (2, 20, 24, 64, 128, 6, 1), (3, 18, 20, 128, 192, 6, 2), (2, 16, 16, 128, 256, 3, 2), (32, 32, 32, 128, 192, 3, 2)])
+def test_lds_dma_ring_tap_table_kernel_equals_the_register_staged_ones(U, case):
+    """igemm3 (K chunks by LDS-DMA into two stages, granules swizzled on the source side, inline-asm fragment reads) against the register-staged tap-table kernels: the same MFMA chain over the same K order, so identical bits - 128- and
+    64-pixel tiles, ragged channel tiles, 36 taps, the four parity classes of a stride-2 transposed layer in one grid, taps
+    outside the image (zero-filled DMAs), column statistics."""
+    _tap_table_ab(U, case, "igemm3", {})
+
+
+def _tap_table_ab(U, case, switch, fixed):
     ops = U.ops
     B, H, W, Ci, Co, k, s = case
     gen = torch.Generator(device=DEV); gen.manual_seed(H * 100 + Ci + k)
@@ -922,7 +935,7 @@ def test_small_problem_tap_table_kernel_equals_the_general_one(U, case):
     out = {}
     try:
         for on in (1, 0):
-            ops.set_config(igemm2=on, conv3x3=0, conv3x3g_pair=0, conv3x3d=0, upconv3x3g=0, upconv3x3q=0)     # everything on the tap-table path
+            ops.set_config(**{switch: on}, conv3x3=0, conv3x3g_pair=0, conv3x3d=0, upconv3x3g=0, upconv3x3q=0, **fixed)     # everything on the tap-table path
             gen.manual_seed(H * 100 + Ci + k)
             g = ops.geom(B, H, W, Ci, Co, k, s)
             Ho, Wo = -(-H // s), -(-W // s)

@@ -22,7 +22,7 @@ class CastDesc(C.Structure):
 class Config(C.Structure):
     """unetrir_config: kernel-selection switches (include/unetrir.h)."""
     _fields_ = [(n, C.c_int) for n in ("conv3x3", "conv3x3g", "conv3x3g_pair", "conv3x3h", "conv3x3s", "conv3x3r", "stem",
-                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d", "conv3x3p", "upconv3x3q", "dyn_tiles", "pw1x1", "igemm2", "bn_fused")]
+                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d", "conv3x3p", "upconv3x3q", "dyn_tiles", "pw1x1", "igemm2", "bn_fused", "igemm3")]
 
 
 class ConvGeom(C.Structure):

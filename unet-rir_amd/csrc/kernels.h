@@ -91,6 +91,11 @@ struct IgemmArgsH {
 // (switch off / too large): the general kernel with 128-pixel tiles.
 int igemm_bf16_tile_m(long long M, int N, int ncls);
 int launch_igemm2_fwd_bf16(const IgemmArgsH* a, int ncls, hipStream_t s);
+// The tap-table launch through an LDS-DMA ring (igemm3_bf16.hip): C % 64 == 0, N > 64.  Same pixel-tile height as the launch it
+// replaces (64 where igemm_bf16_tile_m says so, else 128): the rows of column statistics do not depend on which one runs.
+struct IgemmArgsH4 { IgemmArgsH a[4]; };
+bool igemm3_applies(const IgemmArgsH& a);
+int launch_igemm3_fwd_bf16(const IgemmArgsH* a, int ncls, hipStream_t s);
 // rows of column statistics one tap-table launch writes (= its pixel tiles)
 inline long long igemm_colstat_rows(long long M, int N, int ncls = 1) {
     const int bm = igemm_bf16_tile_m(M, N, ncls);
