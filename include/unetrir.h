@@ -60,7 +60,7 @@ int unetrir_abi_version(void);
  *      the next more general one - for A/B measurements and for parity cross-checks between kernels.  The switches are
  *      read ONCE, at first use, from the environment variables named below (the only variables the library reads) into
  *      this struct; unetrir_set_config replaces the values in effect (tests, A/B scripts: process-global, not
- *      thread-safe - call it while no launch is being issued).  Defaults: all 1 except bn_fused.
+ *      thread-safe - call it while no launch is being issued).  Defaults: all 1 except bn_fused and igemm3.
  *        conv3x3        UNETRIR_CONV3X3        3x3 stride-1: patch-staged kernels at all (0: tap-table implicit GEMM)
  *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels, and 64 output channels from > 64 input channels (64-channel tiles; conv3x3g.hip)
  *        conv3x3g_pair  UNETRIR_CONV3X3G_PAIR  its two-images-per-tile form for images <= 16 wide: 0 off, 1 when it yields
@@ -82,7 +82,9 @@ int unetrir_abi_version(void);
  *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip)
  *        bn_fused       UNETRIR_BN_FUSED       its BatchNormalization passes of tensors <= 64 MB in one launch per direction (bnfused.hip: grid
  *                                              barriers).  DEFAULT 0: measured slower than the separate launches on MI355X (the numbers are in the file)
- *        igemm3         UNETRIR_IGEMM3         bf16 tap-table kernel with LDS-DMA staged K chunks (C % 64 == 0, > 64 output channels: igemm3_bf16.hip) */
+ *        igemm3         UNETRIR_IGEMM3         bf16 tap-table kernel with LDS-DMA staged K chunks (C % 64 == 0, > 64 output channels: igemm3_bf16.hip).
+ *                                              DEFAULT 0: 5-17 % faster than the register-staged kernels launch by launch on warm caches, slower inside
+ *                                              the train step (the numbers are in the file) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
         wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2, bn_fused, igemm3;

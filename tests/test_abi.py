@@ -70,6 +70,6 @@ def test_library_reads_only_the_documented_environment_switches():
     assert "unetrir_abl_set" not in out
     cfg = unet_rir_amd.ops.get_config()
     assert sorted(cfg) == sorted(n for n, _ in unet_rir_amd._lib.Config._fields_)
-    assert all(v == (0 if n == "bn_fused" else 1) for n, v in cfg.items())          # bn_fused: a measured refusal kept behind its switch
+    assert all(v == (0 if n in ("bn_fused", "igemm3") else 1) for n, v in cfg.items())          # measured refusals kept behind their switches
     old = unet_rir_amd.ops.set_config(conv3x3s=0)
     assert old["conv3x3s"] == 1 and unet_rir_amd.ops.get_config()["conv3x3s"] == 0

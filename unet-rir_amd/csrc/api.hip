@@ -32,7 +32,7 @@ unetrir_config load_config() {
     c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
     c.pw1x1 = env_int("UNETRIR_PW1X1", 1);
     c.igemm2 = env_int("UNETRIR_IGEMM2", 1);
-    c.igemm3 = env_int("UNETRIR_IGEMM3", 1);
+    c.igemm3 = env_int("UNETRIR_IGEMM3", 0);
     c.bn_fused = env_int("UNETRIR_BN_FUSED", 0);          // measured slower than the separate launches (bnfused.hip): off unless asked for
     return c;
 }

@@ -10,6 +10,11 @@
 // every barrier and 360 tiles take two rounds; with TWO stages (64 KB at 128-pixel tiles, 48 KB at 64: two to three workgroups per
 // CU) 0.44-0.47 = 90 % of the ingest bound, 5-17 % faster than the register-staged kernels on every shape tried
 // (scripts/micro_igemm.py: 36 x 40 128 -> 128 34.9 -> 30.9 us, 512 -> 1024 s2 @ 32 x 32 102 -> 89 us, 6 x 6 128 -> 128 @ 64 x 64 226 -> 187 us).
+// INSIDE THE TRAIN STEP the order reverses (activations and kernels come from HBM / Infinity Cache, not from an L2 the previous
+// iteration of a benchmark loop left warm; the register-staged kernel keeps three to four 37 KB workgroups on a CU against two here):
+// reference geometry 4.06-4.08 against 3.97-3.99 ms per step, configs[1] single stream 13.36 against 13.25 ms, side-stream schedule
+// equal (scripts/time_refgeom.py, scripts/ab_switch.py igemm3).  The kernel therefore stays behind its switch (igemm3, DEFAULT 0): a
+// measured refusal, and the record of where the tap-table formulation's ceiling is.
 // Same arithmetic (v_mfma_f32_32x32x16_bf16, weights as the row operand, the same K order: IDENTICAL bits), other transport:
 //   * K chunks go global -> LDS by DMA (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction, per-lane gather addresses, taps
 //     outside the image and rows past M / N as out-of-range offsets = zero fill): no registers on the way, no ds_write;
@@ -299,6 +304,9 @@ __device__ __forceinline__ void igemm3_body(const IgemmArgsH& a, const int block
     }
 }
 
+}  // namespace
+
+// (kernels outside the anonymous namespace: profilers print their names)
 template <int BM_, int S>
 __global__ __launch_bounds__(256) void igemm3_fwd_bf16_kernel(const IgemmArgsH a) {
     igemm3_body<BM_, S>(a, blockIdx.x, gridDim.x);
@@ -308,7 +316,6 @@ template <int BM_, int S>
 __global__ __launch_bounds__(256) void igemm3_fwd_bf16_kernel4(const IgemmArgsH4 a4) {
     igemm3_body<BM_, S>(a4.a[blockIdx.y], blockIdx.x, gridDim.x);
 }
-}  // namespace
 
 // C % 64 == 0 (a chunk is 64 channels of ONE tap), N > 64 (128-channel tiles), 32-bit byte offsets into both operands
 bool igemm3_applies(const IgemmArgsH& a) {

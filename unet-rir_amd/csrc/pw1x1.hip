@@ -44,6 +44,9 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+}  // namespace
+
+// (kernel outside the anonymous namespace: profilers print its name)
 // KB = k-blocks of 16 channels (C = 16 KB; C == 8 runs as KB = 1 with the upper half zero), NB = 32-channel output blocks of the
 // workgroup's channel tile (NT = 32 NB <= 64), PD = strips a wave keeps in flight (its pixel fragments live in PD x KB x 4
 // registers: a strip's registers are re-loaded for the strip PD further on as soon as its MFMAs are issued)
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256) void pw1x1_bf16_kernel(const PwArgs a) {
     }
 }
 
+namespace {
 template <int KB, int PD>
 int launch_kb(const PwArgs& a, int nb, unsigned grid, hipStream_t s) {
     if (nb == 2) hipLaunchKernelGGL((pw1x1_bf16_kernel<KB, 2, PD>), dim3(grid), dim3(256), 0, s, a);
