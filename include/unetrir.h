@@ -362,6 +362,17 @@ int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W
                              const float* bias, float* y, int ldy, unetrir_stream_t stream);
 int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy,
                                int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* The head behind conv -> BatchNormalization -> ReLU (dl_models/u_net.py:241-248, :364-371): x is the PRE-BatchNorm tensor of the
+ * last convolutional block and the kernels apply act(x * scale + shift) on their load path (affine = [scale C][shift C] as
+ * unetrir_bn_stats_* / unetrir_bn_inference_affine write it; act 0 none, 1 ReLU, 2 LeakyReLU(0.3); same arithmetic and rounding
+ * as unetrir_bn_apply_bf16 followed by the plain head: identical results) - the activation tensor of that block is never written
+ * or read.  Padding pixels stay zero.  Supported where unetrir_head6x6_bn_supported(W, C) (C = 32 or 64, switch head_mfma on);
+ * UNETRIR_EINVAL otherwise. */
+int unetrir_head6x6_bn_supported(int W, int C);
+int unetrir_head6x6_fwd_bn_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* affine, int act,
+                                const float* w, const float* bias, float* y, int ldy, unetrir_stream_t stream);
+int unetrir_head6x6_wgrad_bn_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* affine, int act,
+                                  const unetrir_bf16* dy, int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
 /* ---- fused column statistics (bf16).  The 3x3 stride-1 kernels that serve most layers can emit, per 16 x 32 pixel tile,
  *      the per-channel (sum, sum of squares) of the bf16 output they store: colstat is [rows][N][2] floats with N the
  *      convolution's output channels (forward: Cout, data gradient: Cin).  BatchNormalization statistics (dl_models/

@@ -1,5 +1,5 @@
 """A/B of one kernel-selection switch on the full train step, alternating two engines in ONE process (cfg 2, bf16):
-python scripts/ab_switch.py conv3x3s [--no-overlap] [rounds]"""
+python scripts/ab_switch.py conv3x3s [--no-overlap] [rounds]        (attr:head_bn flips an ENGINE attribute instead of a library switch)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,13 +7,23 @@ import unet_rir_amd as U
 import bench
 
 name = sys.argv[1]
+attr = name[5:] if name.startswith("attr:") else None
 overlap = "--no-overlap" not in sys.argv
 rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 6
 dev = torch.device("cuda:0")
 trainers = {}
+def flip(val, eng=None):
+    if attr is None:
+        U.ops.set_config(**{name: val})
+    elif eng is not None:
+        assert getattr(eng, attr) in (True, False) and getattr(eng, attr + "_supported", True)
+        setattr(eng, attr, bool(val))
+
+
 for val in (1, 0):
-    U.ops.set_config(**{name: val})
+    flip(val)
     eng = U.UNetEngine(256, 256, 32, F0=64, k=3, device=dev, dtype="bf16", overlap_wgrad=overlap)
+    flip(val, eng)
     g = torch.Generator(); g.manual_seed(0)
     eng.reset_parameters(g)
     trainers[val] = U.Trainer(eng, lr=5e-7)
@@ -21,7 +31,7 @@ batch = bench.synthetic_batch(32, 256, 256, dev, 1234)
 res = {0: [], 1: []}
 for r in range(rounds):
     for val in (1, 0):
-        U.ops.set_config(**{name: val})
+        flip(val)
         tr = trainers[val]
         for _ in range(2):
             tr.step(*batch)

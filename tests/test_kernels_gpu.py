@@ -1036,3 +1036,38 @@ def test_fused_batchnorm_launches_equal_the_separate_ones(U, dtype, case):
     mean, var = yd.mean(0), yd.var(0, unbiased=False)
     want = torch.nn.functional.leaky_relu((yd - mean) / torch.sqrt(var + 1e-3) * gamma.double() + beta.double() + skip.base.double().view(P, C), 0.3)
     assert float((res[1]["y"].double().view(P, C) - want).abs().max()) <= (1e-5 if dtype == "f32" else 2e-2) * float(want.abs().max())
+
+
+@pytest.mark.parametrize("case", [(2, 37, 50, 32, 1), (3, 40, 64, 64, 1), (1, 20, 300, 64, 2), (2, 33, 256, 32, 0)])
+def test_head_with_batchnorm_on_its_load_path_equals_apply_then_head(U, case):
+    """unetrir_head6x6_{fwd,wgrad}_bn_bf16: the 6 x 6 head (dl_models/u_net.py:248) reading the PRE-BatchNorm tensor of the last
+    convolutional block and applying act(x * scale + shift) while it loads - against BatchNorm-apply into an activation tensor
+    followed by the plain head kernels: identical logits and identical kernel gradients (same arithmetic, same rounding, zero padding
+    of the ACTIVATION), images wider than one column block included."""
+    ops = U.ops
+    B, H, W, C, act = case
+    assert ops.head6x6_bn_supported(W, C)
+    gen = torch.Generator(device=DEV); gen.manual_seed(H * 31 + W)
+    x = ops.Act(((torch.rand((B, H, W, C + 8), device=DEV, generator=gen) - 0.5) * 4).to(torch.bfloat16), 0, C)
+    affine = torch.cat([torch.rand(C, device=DEV, generator=gen) + 0.5, torch.rand(C, device=DEV, generator=gen) - 0.5])
+    w = (torch.rand((8, 6, 6, C), device=DEV, generator=gen) - 0.5) * 0.2
+    bias = torch.rand(8, device=DEV, generator=gen) - 0.5
+    a = ops.Act(torch.empty((B, H, W, C), dtype=torch.bfloat16, device=DEV))
+    ops.bn_apply(x, affine, a, relu=act)
+    y0, y1 = ops.new_act(B, H, W, 4, DEV), ops.new_act(B, H, W, 4, DEV)
+    ops.head6x6_fwd(a, w, bias, y0)
+    ops.head6x6_fwd_bn(x, affine, act, w, bias, y1)
+    dy = ops.Act(((torch.rand((B, H, W, 8), device=DEV, generator=gen) - 0.5)).to(torch.bfloat16))
+    ws = ops.Workspace(DEV)
+    dw0, dw1 = torch.zeros((8, 6, 6, C), device=DEV), torch.zeros((8, 6, 6, C), device=DEV)
+    ops.head6x6_wgrad(a, dy, dw0, ws)
+    ops.head6x6_wgrad_bn(x, affine, act, dy, dw1, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.base, y1.base)
+    assert torch.equal(dw0, dw1) and float(dw0[:2].abs().max()) > 0.0
+    # against the definition (fp64) of what the pair computes
+    ad = a.base.double().permute(0, 3, 1, 2)
+    want = torch.nn.functional.conv2d(torch.nn.functional.pad(ad, (2, 3, 2, 3)), w[:2].double().permute(0, 3, 1, 2).to(torch.bfloat16).double()) \
+        + bias[:2].double().view(1, 2, 1, 1)
+    got = y1.base[..., :2].double().permute(0, 3, 1, 2)
+    assert float((got - want).abs().max()) <= 1e-4 * (float(want.abs().max()) + 1.0)

@@ -126,6 +126,11 @@ _SIGS = {
                                            C.c_int, c_stream]),
     "unetrir_head6x6_wgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                              c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "unetrir_head6x6_bn_supported": (C.c_int, [C.c_int, C.c_int]),
+    "unetrir_head6x6_fwd_bn_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
+                                              C.c_int, c_stream]),
+    "unetrir_head6x6_wgrad_bn_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
+                                                c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_stage_h2d": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), c_stream]),
     "unetrir_conv2d_colstat_rows_bf16": (C.c_longlong, [C.POINTER(ConvGeom), C.c_int, C.c_int]),
     "unetrir_conv3x3_kernel_id_bf16": (C.c_int, [C.POINTER(ConvGeom), C.c_int, C.c_int]),

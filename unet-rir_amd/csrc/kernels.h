@@ -141,9 +141,12 @@ struct Conv3Args {
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s);
 int launch_conv3x3r_bf16(const Conv3Args& a, hipStream_t s);
 bool head_mfma_applies(int W, int C);
-int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s);
+// affine != nullptr: x is the pre-BatchNorm tensor, act(x * scale + shift) is applied on the load path (head_mfma_bn_applies)
+bool head_mfma_bn_applies(int W, int C);
+int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s,
+                         const float* affine = nullptr, int act = 0);
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
-                           int* nblk_out, hipStream_t s);
+                           int* nblk_out, hipStream_t s, const float* affine = nullptr, int act = 0);
 bool head_dgrad_mfma_applies(int W, int C);
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, int C, void* dx, int lddx, hipStream_t s);
 bool upconv3x3g_applies(const Conv3Args& a);

@@ -299,6 +299,13 @@ class UNetEngine(DeviceCounters):
             self.wg_stream, self.opt_stream = self.rt.concurrent_streams(2) if overlap_wgrad else (None, None)
         self.ws_w = ops.Workspace(self.device, self.ws.nbytes) if overlap_wgrad else self.ws
         self.head_direct = ops.head6x6_supported(self.ch[0])
+        # The head kernels can take the PRE-BatchNorm tensor of dec1.cb1b and apply BatchNorm + ReLU on their load path, so that this
+        # block's activation tensor (268 MB at configs[1]) is never written or read (csrc/head_mfma.hip).  Identical results (tested),
+        # but MEASURED SLOWER: the BatchNorm-apply pass it removes takes 105 us, the two head kernels gain 53 + 58 us of vector work
+        # they cannot hide - off unless asked for (`head_bn = True` where `head_bn_supported`).
+        self.head_bn_supported = bool(self.head_direct and self.dtype == "bf16" and self.batchnorm and self.depth >= 1 and
+                                      ops.head6x6_bn_supported(self.W, self.ch[0]))
+        self.head_bn = False
         if self.head_direct:
             self.ws.reserve(512 * 2 * 36 * self.ch[0] * 4)
             self.ws_w.reserve(512 * 2 * 36 * self.ch[0] * 4)
@@ -668,6 +675,31 @@ class UNetEngine(DeviceCounters):
         ops.bn_colstat_act_add(buf, rows, y, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name], out, 1, None,
                                self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
 
+    def _conv_bn_stats_fwd(self, name, x: Act, y: Act):
+        """Conv2D -> BatchNormalization statistics only (affine, saved, moving statistics): the consumer applies BatchNorm + ReLU on
+        its load path (the head: csrc/head_mfma.hip)."""
+        p = self.p
+        rows, buf = self._colstat(name, 0, x, y.C) if self.training else (0, None)
+        if rows:
+            ops.conv2d_fwd_colstat(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y, buf)
+            ops.bn_stats_colstat(buf, rows, y.P, y.C, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name],
+                                 self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
+            return
+        ops.conv2d_fwd(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y)
+        if self.training:
+            ops.bn_stats(y, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name], self.ws,
+                         self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
+        else:
+            ops.bn_inference_affine(p[name + ".gamma"], p[name + ".beta"], self.moving[name + ".moving_mean"],
+                                    self.moving[name + ".moving_variance"], BN_EPS, self.bn_affine[name])
+
+    def head_input(self):
+        """The activation in front of the head, relu(bn(dec1.cb1b)).  With `head_bn` it exists only inside the head kernels; it is
+        written here on request (inspection, tests) from the pre-BatchNorm tensor and the affine of the last forward pass."""
+        if self.head_bn:
+            ops.bn_apply(self.yb[1], self.bn_affine["dec1.cb1b"], self.ab[1], relu=True)
+        return self.ab[1] if self.depth >= 1 else self.a[1]
+
     def _dgrad_colsum(self, name, dy: Act, dx: Act, bias_grad, c0, c_n):
         """Data gradient of conv `name` plus the bias gradient of the layer that produced its input (channels
         [c0, c0+c_n) of dx summed over pixels), fused into the dgrad epilogue where the serving kernel allows."""
@@ -745,9 +777,14 @@ class UNetEngine(DeviceCounters):
             ops.conv2d_transpose_fwd(self.geo[f"dec{l}.up"], cur, self.wb(f"dec{l}.up.kernel"), p[f"dec{l}.up.bias"],
                                      self.cat[l].slice(c, c))
             self._conv_bn_relu_fwd(f"dec{l}.cb1a", self.cat[l], self.ya[l], self.aa[l])
-            self._conv_bn_relu_fwd(f"dec{l}.cb1b", self.aa[l], self.yb[l], self.ab[l])
+            if l == 1 and self.head_bn:
+                self._conv_bn_stats_fwd("dec1.cb1b", self.aa[1], self.yb[1])         # ab[1] = relu(bn(yb[1])) exists only inside the head kernels
+            else:
+                self._conv_bn_relu_fwd(f"dec{l}.cb1b", self.aa[l], self.yb[l], self.ab[l])
             cur = self.ab[l]
-        if self.head_direct:
+        if self.head_bn:
+            ops.head6x6_fwd_bn(self.yb[1], self.bn_affine["dec1.cb1b"], 1, p["head.kernel"], p["head.bias"], self.logits)
+        elif self.head_direct:
             ops.head6x6_fwd(cur, p["head.kernel"], p["head.bias"], self.logits)
         else:
             ops.conv2d_fwd(self.geo["head"], cur, p["head.kernel"], p["head.bias"], self.logits)
@@ -817,7 +854,10 @@ class UNetEngine(DeviceCounters):
                 on_ready(off)
 
         gl = self.g_logits
-        if self.head_direct:
+        if self.head_bn:
+            with self._wg() as ws_:
+                ops.head6x6_wgrad_bn(self.yb[1], self.bn_affine["dec1.cb1b"], 1, gl, g["head.kernel"], ws_)
+        elif self.head_direct:
             with self._wg() as ws_:
                 ops.head6x6_wgrad(self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws_)   # rows 2,3 of the padded kernel stay 0
         else:
