@@ -71,22 +71,22 @@ for (B, HW, Ci, Co) in [(32, 128, 128, 128), (32, 64, 256, 256)]:
     total += screen(f"conv3x3p fwd  {Ci}->{Co} @{HW} B={B}", lambda: ops.conv2d_fwd(g, x, wh, None, out), out.base)
     total += screen(f"conv3x3p dgrad {Ci}->{Co} @{HW} B={B}", lambda: ops.conv2d_dgrad(g, y, wt, dx), dx.base)
 # conv3x3s at its launched size: 1 024 strip segments drawn at run time, the column statistics leave the registers per segment
-for (B, HW) in [(32, 256), (32, 128)]:
-    g = ops.geom(B, HW, HW, 64, 64, 3, 1)
-    x, y = ops.Act(rnd((B, HW, HW, 64))), ops.Act(rnd((B, HW, HW, 64)))
-    wh, wt = rnd((64, 9, 64), 0.1), rnd((64, 9, 64), 0.1)
-    out = ops.Act(torch.empty((B, HW, HW, 64), dtype=torch.bfloat16, device=dev))
-    dx = ops.Act(torch.empty((B, HW, HW, 64), dtype=torch.bfloat16, device=dev))
+for (B, HW, CH) in [(32, 256, 64), (32, 128, 64), (32, 128, 32), (32, 256, 32)]:
+    g = ops.geom(B, HW, HW, CH, CH, 3, 1)
+    x, y = ops.Act(rnd((B, HW, HW, CH))), ops.Act(rnd((B, HW, HW, CH)))
+    wh, wt = rnd((CH, 9, CH), 0.1), rnd((CH, 9, CH), 0.1)
+    out = ops.Act(torch.empty((B, HW, HW, CH), dtype=torch.bfloat16, device=dev))
+    dx = ops.Act(torch.empty((B, HW, HW, CH), dtype=torch.bfloat16, device=dev))
     assert ops.conv3x3_kernel(g, 0, x) == "conv3x3s"
     rows = ops.conv2d_colstat_rows(g, 0, x)
-    cst = torch.zeros((rows, 64, 2), device=dev)
+    cst = torch.zeros((rows, CH, 2), device=dev)
     both = torch.zeros(out.base.numel() + cst.numel(), device=dev)
 
     def fwd_stats():
         ops.conv2d_fwd_colstat(g, x, wh, None, out, cst)
         both[:out.base.numel()].copy_(out.base.flatten()); both[out.base.numel():].copy_(cst.flatten())
-    total += screen(f"conv3x3s fwd + statistics 64->64 @{HW} B={B} ({rows} rows)", fwd_stats, both)
-    total += screen(f"conv3x3s dgrad 64->64 @{HW} B={B}", lambda: ops.conv2d_dgrad(g, y, wt, dx), dx.base)
+    total += screen(f"conv3x3s fwd + statistics {CH}->{CH} @{HW} B={B} ({rows} rows)", fwd_stats, both)
+    total += screen(f"conv3x3s dgrad {CH}->{CH} @{HW} B={B}", lambda: ops.conv2d_dgrad(g, y, wt, dx), dx.base)
 for (B, H, Ci, Co) in [(32, 256, 64, 128), (32, 128, 128, 256)]:
     g = ops.geom(B, H, H, Ci, Co, 3, 2)
     x = ops.Act(rnd((B, H, H, Ci)))

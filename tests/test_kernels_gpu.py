@@ -332,6 +332,8 @@ BF16_CONV_CASES = [
     # strip kernel (conv3x3s, 64 -> 64): ragged rows and columns; many one-tile segments; whole-column strips of 3 tiles on
     # 256 workgroups; two jobs of 2 tiles per workgroup
     (2, 21, 60, 64, 64, 3, 1), (3, 64, 96, 64, 64, 3, 1), (16, 24, 512, 64, 64, 3, 1), (32, 16, 512, 64, 64, 3, 1),
+    # ... and its 32 -> 32 form (64-byte pixels, one K chunk): the same shapes, and the reference geometry's 144 x 160
+    (2, 21, 60, 32, 32, 3, 1), (3, 64, 96, 32, 32, 3, 1), (16, 24, 512, 32, 32, 3, 1), (32, 16, 512, 32, 32, 3, 1), (4, 144, 160, 32, 32, 3, 1),
 ]
 
 
@@ -542,7 +544,8 @@ def test_dense_split_k(U, B, K, N):
 
 @pytest.mark.parametrize("case", [(2, 40, 70, 64, 160, 3, 1), (1, 33, 64, 96, 96, 3, 1), (2, 30, 64, 32, 64, 3, 1), (1, 16, 32, 16, 24, 3, 1),
                                   (5, 16, 16, 96, 128, 3, 1), (4, 24, 12, 96, 160, 3, 1),
-                                  (2, 21, 60, 64, 64, 3, 1), (3, 64, 96, 64, 64, 3, 1), (16, 24, 512, 64, 64, 3, 1)])
+                                  (2, 21, 60, 64, 64, 3, 1), (3, 64, 96, 64, 64, 3, 1), (16, 24, 512, 64, 64, 3, 1),
+                                  (2, 21, 60, 32, 32, 3, 1), (3, 64, 96, 32, 32, 3, 1), (16, 24, 512, 32, 32, 3, 1)])
 def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     """Conv epilogue statistics (conv3x3g / conv3x3r<4,1>): the per-tile (sum, sum of squares) rows must add up to the
     statistics of the bf16 tensor the same launch stored, forward and data gradient, and BN statistics / bias gradients
@@ -559,7 +562,8 @@ def test_conv_fused_column_statistics_bf16(U, case, monkeypatch):
     ops.cast_weight_bf16(w32, wf, Co, 9, Ci, Ci)
     rows = ops.conv2d_colstat_rows(g, 0, xa)
     paired = W <= 16 and B >= 2 and Co > 64 and Ci % 32 == 0          # narrow images: two per tile
-    if (Ci, Co) == (64, 64):          # strip kernel: one row per (job = vertical segment of a 32-wide strip, wave), whoever serves the job
+    if (Ci, Co) in ((64, 64), (32, 32)):          # strip kernel: one row per (job = vertical segment of a 32-wide strip, wave), whoever serves the job
+        assert ops.conv3x3_kernel(g, 0, xa) == "conv3x3s"
         assert rows % 8 == 0 and 0 < rows <= 8 * B * ((W + 31) // 32) * ((H + 7) // 8)
     else:
         assert rows == ((B + 1) // 2 if paired else B) * ((H + 15) // 16) * ((W + 31) // 32)

@@ -54,42 +54,61 @@ __device__ __forceinline__ float row_sum16(float v) {       // sum over the 16 l
 constexpr int SPC = 34;                         // patch columns
 constexpr int STR = 8;                          // tile rows
 constexpr int SNPX = (STR + 2) * SPC;           // 340 patch pixels
-constexpr int SP_INSTR = (SNPX + 7) / 8;        // 43 wave-instructions of 8 pixels x 128 B
-constexpr int SP_BYTES = SP_INSTR * 1024;       // 44032
-constexpr int SROW = SPC * 128;                 // 4352: patch row pitch
-constexpr int SW_BYTES = 72 * 1024;             // 73728: [9 taps][2 chunks][4 channel tiles] fragment blocks
-constexpr int SSMEM = SW_BYTES + 2 * SP_BYTES;  // 161792 of 163840
-constexpr int STICK = SSMEM;                    // 4 words: the first two tickets, then the hand-over words of even / odd jobs
-constexpr int SCARRY = 8;                       // wave-instructions (64 pixels) of the next patch that come from this one through LDS
 constexpr uint32_t OOB = 0xF0000000u;
+// CH = 64 (the layers the kernel was built for) or 32 (round 3: the full-resolution 32 -> 32 layers of the residual graphs,
+// dl_models/res_ae.py:466, and of the reference's own number_filters_0 = 32, main_training.py:154-161): values for 64 / 32 channels
+template <int CH> struct SC {
+    static constexpr int PIXB = CH * 2;                        // 128 / 64 bytes per pixel
+    static constexpr int PPI = 1024 / PIXB;                    // 8 / 16 pixels per DMA wave-instruction
+    static constexpr int GPP = PIXB / 16;                      // 8 / 4 16-byte granules per pixel
+    static constexpr int KCN = CH / 32;                        // 2 / 1 K chunks of 32 input channels
+    static constexpr int NT = CH / 16;                         // 4 / 2 channel tiles of 16
+    static constexpr int NH = CH / 32;                         // 2 / 1 groups of 8 channels a lane stores per pixel
+    static constexpr int P_INSTR = (SNPX + PPI - 1) / PPI;     // 43 / 22 wave-instructions per patch
+    static constexpr int P_BYTES = P_INSTR * 1024;             // 44032 / 22528
+    static constexpr int ROWB = SPC * PIXB;                    // 4352 / 2176: patch row pitch
+    static constexpr int NBLK = 9 * KCN * NT;                  // 72 / 18 kernel fragment blocks [9 taps][KCN chunks][NT channel tiles]
+    static constexpr int W_BYTES = NBLK * 1024;                // 73728 / 18432
+    static constexpr int SMEM = W_BYTES + 2 * P_BYTES;         // 161792 (of 163840) / 63488
+    static constexpr int TICK = SMEM;                          // 4 words: the first two tickets, then the hand-over words of even / odd jobs
+    static constexpr int CARRY = 64 / PPI;                     // 8 / 4 wave-instructions (64 pixels) of the next patch that come from this one through LDS
+    static constexpr int NJ = (P_INSTR + 7) / 8;               // 6 / 3 patch DMA instructions per wave
+    static constexpr int NU = 9 * KCN;                         // 18 / 9 sub-steps of the K loop
+    static constexpr int NG = 3 * KCN;                         // 6 / 3 groups (chunk, horizontal tap)
+    static constexpr int WP = 9 * CH * 2;                      // 1152 / 576: byte pitch of a kernel row [n][tap][c]
+};
 
 // The K loop is 18 sub-steps u = (group g = (chunk kc, horizontal tap dx), vertical tap dy): 8 MFMAs (2 output rows x 4 channel
 // tiles) on 4 kernel fragments and two patch-row fragments.  Fragments of sub-step u+1 are requested before the MFMAs of u:
 // 4 kernel blocks into the other of two register sets, and the ONE patch row u+1 adds (two at the start of a group, into
 // the other patch set).
-template <int U>
-__device__ __forceinline__ void issue_reads(u32x4 (&A)[2][4], u32x4 (&B)[2][4], uint32_t wa, uint32_t wa8, const uint32_t (&pa)[6]) {
+template <int CH, int U>
+__device__ __forceinline__ void issue_reads(u32x4 (&A)[2][SC<CH>::NT], u32x4 (&B)[2][4], uint32_t wa, uint32_t wa8, const uint32_t (&pa)[SC<CH>::NG]) {
+    using T = SC<CH>;
     constexpr int G = U / 3, DY = U % 3, KC = G / 3, DX = G % 3;
-    constexpr int BLK = ((DY * 3 + DX) * 2 + KC) * 4;            // block = (tap * 2 + kc) * 4 + t, tap = dy * 3 + dx
-    if constexpr (DY == 0) { DSR128(B[G & 1][0], pa[G], 0 * SROW); DSR128(B[G & 1][1], pa[G], 1 * SROW); }
-    if constexpr (DY == 1) DSR128(B[G & 1][2], pa[G], 2 * SROW);
-    if constexpr (DY == 2) DSR128(B[G & 1][3], pa[G], 3 * SROW);
-    if constexpr (BLK < 64) {                                     // taps 0..7: 16-bit offsets from wa; tap 8 from wa8 = wa + 64 KB
+    constexpr int BLK = ((DY * 3 + DX) * T::KCN + KC) * T::NT;   // block = (tap * KCN + kc) * NT + t, tap = dy * 3 + dx
+    if constexpr (DY == 0) { DSR128(B[G & 1][0], pa[G], 0 * T::ROWB); DSR128(B[G & 1][1], pa[G], 1 * T::ROWB); }
+    if constexpr (DY == 1) DSR128(B[G & 1][2], pa[G], 2 * T::ROWB);
+    if constexpr (DY == 2) DSR128(B[G & 1][3], pa[G], 3 * T::ROWB);
+    if constexpr (BLK < 64) {                                     // 16-bit offsets from wa; blocks from 64 on (tap 8 at 64 channels) from wa8 = wa + 64 KB
         DSR128(A[U & 1][0], wa, (BLK + 0) * 1024); DSR128(A[U & 1][1], wa, (BLK + 1) * 1024);
-        DSR128(A[U & 1][2], wa, (BLK + 2) * 1024); DSR128(A[U & 1][3], wa, (BLK + 3) * 1024);
+        if constexpr (T::NT == 4) { DSR128(A[U & 1][2], wa, (BLK + 2) * 1024); DSR128(A[U & 1][3], wa, (BLK + 3) * 1024); }
     } else {
         DSR128(A[U & 1][0], wa8, (BLK - 64 + 0) * 1024); DSR128(A[U & 1][1], wa8, (BLK - 64 + 1) * 1024);
-        DSR128(A[U & 1][2], wa8, (BLK - 64 + 2) * 1024); DSR128(A[U & 1][3], wa8, (BLK - 64 + 3) * 1024);
+        if constexpr (T::NT == 4) { DSR128(A[U & 1][2], wa8, (BLK - 64 + 2) * 1024); DSR128(A[U & 1][3], wa8, (BLK - 64 + 3) * 1024); }
     }
 }
 
-template <int U>
-__device__ __forceinline__ void k_substeps(u32x4 (&A)[2][4], u32x4 (&B)[2][4], f32x4 (&acc)[2][4], uint32_t wa, uint32_t wa8,
-                                           const uint32_t (&pa)[6]) {
+template <int CH, int U>
+__device__ __forceinline__ void k_substeps(u32x4 (&A)[2][SC<CH>::NT], u32x4 (&B)[2][4], f32x4 (&acc)[2][SC<CH>::NT], uint32_t wa, uint32_t wa8,
+                                           const uint32_t (&pa)[SC<CH>::NG]) {
+    using T = SC<CH>;
     constexpr int G = U / 3, DY = U % 3;
-    if constexpr (U + 1 < 18) {
-        issue_reads<U + 1>(A, B, wa, wa8, pa);
-        if constexpr ((U + 1) % 3 == 0) LGKM_WAIT(6); else LGKM_WAIT(5);      // everything but the reads just issued
+    if constexpr (U + 1 < T::NU) {
+        issue_reads<CH, U + 1>(A, B, wa, wa8, pa);
+        // everything but the reads just issued (NT kernel blocks + two patch rows at the start of a group, else one)
+        if constexpr (T::NT == 4) { if constexpr ((U + 1) % 3 == 0) LGKM_WAIT(6); else LGKM_WAIT(5); }
+        else { if constexpr ((U + 1) % 3 == 0) LGKM_WAIT(4); else LGKM_WAIT(3); }
     } else {
         LGKM_WAIT(0);
     }
@@ -97,15 +116,17 @@ __device__ __forceinline__ void k_substeps(u32x4 (&A)[2][4], u32x4 (&B)[2][4], f
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) MMA16(acc[o][t], A[U & 1][t], B[G & 1][o + DY]);
+        for (int t = 0; t < T::NT; ++t) MMA16(acc[o][t], A[U & 1][t], B[G & 1][o + DY]);
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (U + 1 < 18) k_substeps<U + 1>(A, B, acc, wa, wa8, pa);
+    if constexpr (U + 1 < T::NU) k_substeps<CH, U + 1>(A, B, acc, wa, wa8, pa);
 }
 }  // namespace
 
 // abl (ablation build only): 1 no patch DMA after the first tile, 2 no output stores, 4 no MFMA loop
+template <int CH>
 __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a, int nseg, int seglen, int per_xcd, unsigned* sched, int abl) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SSMEM + 16];
+    using T = SC<CH>;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[T::SMEM + 16];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     int kfix = 0;                                         // fixed assignment: tickets handed out so far (thread 0)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     if (tid == 0) {                                       // the first two tickets: one round trip
-        unsigned* tk = reinterpret_cast<unsigned*>(smem + STICK);
+        unsigned* tk = reinterpret_cast<unsigned*>(smem + T::TICK);
         if (ctr) { const unsigned t = __hip_atomic_fetch_add(ctr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); tk[0] = t; tk[1] = t + 1; }
         else { tk[0] = (unsigned)wg; tk[1] = (unsigned)wg + gridDim.x; kfix = 2; }
     }
@@ -134,48 +155,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     // ---- the kernel, once per workgroup, in fragment order.  Block (tap, kc, t), lane l: row r = l & 15 of the MFMA A operand is
     // output channel n(t, r) = 32 (t >> 1) + 8 (r >> 2) + 4 (t & 1) + (r & 3); k group l >> 4 = input channels 32 kc + 8 (l >> 4) ..
     {
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, 64 * 9 * 64 * 2, 0x00020000);
-        const uint32_t vw = (uint32_t)((8 * (l15 >> 2) + (l15 & 3)) * 1152 + lq * 16);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, CH * 9 * CH * 2, 0x00020000);
+        const uint32_t vw = (uint32_t)((8 * (l15 >> 2) + (l15 & 3)) * T::WP + lq * 16);
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {
+        for (int j = 0; j < (T::NBLK + 7) / 8; ++j) {
             const int b = wave + 8 * j;
-            const int t = b & 3, kc = (b >> 2) & 1, tap = b >> 3;
+            if (b >= T::NBLK) continue;                          // wave-uniform
+            const int t = b % T::NT, kc = (b / T::NT) % T::KCN, tap = b / (T::NT * T::KCN);
             const int tapsrc = (a.flip & 1) ? 8 - tap : tap;
-            const uint32_t so = (uint32_t)((32 * (t >> 1) + 4 * (t & 1)) * 1152 + tapsrc * 128 + kc * 64);
+            const uint32_t so = (uint32_t)((32 * (t >> 1) + 4 * (t & 1)) * T::WP + tapsrc * T::PIXB + kc * 64);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(smem + b * 1024), 16, vw + so, 0, 0, 0);
         }
     }
 
-    // ---- patch DMA: wave-instruction i covers patch pixels 8 i .. 8 i + 7, lane l the 16-byte granule (l & 7) of pixel 8 i + (l >> 3).
+    // ---- patch DMA: wave-instruction i covers patch pixels PPI i .. PPI i + PPI - 1 (8 of 128 B, or 16 of 64 B), lane l the 16-byte
+    // granule l % GPP of pixel PPI i + l / GPP.
     // This wave issues instructions wave, wave + 8, ...: their patch row / column are fixed per lane, the byte offset of a
     // strip's column part is computed once per job, a tile only adds its row offset and the row bound.
-    int dma_pr[6], dma_pc[6];
+    int dma_pr[T::NJ], dma_pc[T::NJ];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int p = 8 * (wave + 8 * j) + (lane >> 3);
+    for (int j = 0; j < T::NJ; ++j) {
+        const int p = T::PPI * (wave + 8 * j) + lane / T::GPP;
         dma_pr[j] = p < SNPX ? p / SPC : 1 << 20;              // past the patch: never a valid row
         dma_pc[j] = p - (p / SPC) * SPC;
     }
-    int dma_x[6];                                            // ((pr - 1) W + ix) ldi 2 + 16 sg for this job's strip, or INT_MIN
+    int dma_x[T::NJ];                                        // ((pr - 1) W + ix) ldi 2 + 16 sg for this job's strip, or INT_MIN
     auto image_rsrc = [&](int img) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(in + (size_t)img * a.H * a.W * a.ldi), (short)0,
-                                                 (int)((((size_t)a.H * a.W - 1) * a.ldi + 64) * 2), 0x00020000);
+                                                 (int)((((size_t)a.H * a.W - 1) * a.ldi + CH) * 2), 0x00020000);
     };
-    auto job_columns = [&](int x0, int (&dx_)[6]) {
+    // source granule of LDS slot l % GPP: the granules of a pixel are XOR-swizzled with its column (64 channels: 8 granules, key
+    // column & 7; 32 channels: 4 granules, key (column >> 2) & 3 - two pixels share a 128-byte line, four consecutive ones a key)
+    auto job_columns = [&](int x0, int (&dx_)[T::NJ]) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < T::NJ; ++j) {
             const int ix = x0 - 1 + dma_pc[j];
-            const int sg = (lane & 7) ^ (dma_pc[j] & 7);
+            const int sg = CH == 64 ? ((lane & 7) ^ (dma_pc[j] & 7)) : ((lane & 3) ^ ((dma_pc[j] >> 2) & 3));
             dx_[j] = (unsigned)ix < (unsigned)a.W ? (((dma_pr[j] - 1) * a.W + ix) * a.ldi + sg * 8) * 2 : INT32_MIN;
         }
     };
-    auto issue_patch = [&](const __amdgpu_buffer_rsrc_t& rs, const int (&dx_)[6], int y0, int first, int buf) {
-        unsigned char* dst = smem + SW_BYTES + buf * SP_BYTES;
+    auto issue_patch = [&](const __amdgpu_buffer_rsrc_t& rs, const int (&dx_)[T::NJ], int y0, int first, int buf) {
+        unsigned char* dst = smem + T::W_BYTES + buf * T::P_BYTES;
         const int rowoff = y0 * a.W * a.ldi * 2;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < T::NJ; ++j) {
             const int i = wave + 8 * j;
-            if (i < first || i >= SP_INSTR) continue;           // wave-uniform
+            if (i < first || i >= T::P_INSTR) continue;         // wave-uniform
             const bool ok = dx_[j] != INT32_MIN && (unsigned)(y0 - 1 + dma_pr[j]) < (unsigned)a.H;
             const uint32_t off = ok ? (uint32_t)(dx_[j] + rowoff) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst + i * 1024), 16, off, 0, 0, 0);
@@ -191,24 +216,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
 
     // ---- fragment read addresses
     const uint32_t wa = lds0 + lane * 16, wa8 = wa + 65536;
-    uint32_t pbase[2][3];                             // + buf * SP_BYTES + r * SROW
+    uint32_t pbase[T::KCN][3];                        // + buf * P_BYTES + r * ROWB
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         const int col = 16 * ph + l15 + dx;
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
-            pbase[kc][dx] = lds0 + SW_BYTES + (uint32_t)((2 * rp * SPC + col) * 128 + (((kc * 4 + lq) ^ (col & 7)) << 4));
+        for (int kc = 0; kc < T::KCN; ++kc)
+            pbase[kc][dx] = lds0 + T::W_BYTES + (uint32_t)((2 * rp * SPC + col) * T::PIXB +
+                                                        ((CH == 64 ? ((kc * 4 + lq) ^ (col & 7)) : (lq ^ ((col >> 2) & 3))) << 4));
     }
 
     // ---- epilogue constants: lane (pixel column l15, quarter lq) holds channels 32 h + 8 lq .. + 8 (h = 0, 1) of its pixel
-    float bias_[2][8];
+    float bias_[T::NH][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < T::NH; ++h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bias_[h][e] = a.bias ? a.bias[32 * h + 8 * lq + e] : 0.f;
-    float cs_s[2][8], cs_q[2][8];
+    float cs_s[T::NH][8], cs_q[T::NH][8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < T::NH; ++h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { cs_s[h][e] = 0.f; cs_q[h][e] = 0.f; }
     __bf16* __restrict__ out = (__bf16*)a.out;
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
 
     // D row 4 lq + j of channel tile t is channel 32 (t >> 1) + 8 lq + 4 (t & 1) + j of pixel column l15: 16 bytes per lane and
     // (row, half) straight from the accumulators.  Returns the number of store instructions issued (wave-uniform).
-    auto epilogue = [&](const f32x4 (&acc)[2][4], int img, int x0, int y0) -> int {
+    auto epilogue = [&](const f32x4 (&acc)[2][T::NT], int img, int x0, int y0) -> int {
         const int x = x0 + 16 * ph + l15;
         int nst = 0;
 #pragma unroll
@@ -226,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
             const bool ok = x < a.W;
             const size_t pix = ((size_t)img * a.H + y) * a.W + x;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < T::NH; ++h) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[o][2 * h + (e >> 2)][e & 3] + bias_[h][e];
@@ -251,12 +277,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
         return nst;
     };
 
-    // ---- column statistics of a finished job: over the 16 pixel columns of a lane group, then lane l15 == 0 writes its 2 x 8 channels
-    //      of the row of (job, this wave).  8 store instructions (wave-uniform), counted by the caller's vmcnt waits.
+    // ---- column statistics of a finished job: over the 16 pixel columns of a lane group, then lane l15 == 0 writes its NH x 8 channels
+    //      of the row of (job, this wave).  4 NH store instructions (wave-uniform), counted by the caller's vmcnt waits.
     auto flush_stats = [&](int jobid) {
-        float* row = a.colstat + ((size_t)jobid * 8 + wave) * 128;
+        float* row = a.colstat + ((size_t)jobid * 8 + wave) * (2 * CH);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < T::NH; ++h) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { cs_s[h][e] = row_sum16(cs_s[h][e]); cs_q[h][e] = row_sum16(cs_q[h][e]); }
 #pragma unroll
@@ -276,8 +302,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     unsigned tk0, tk1;
     {
         unsigned v0, v1;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(lds0 + STICK));
-        asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(v1) : "v"(lds0 + STICK));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(lds0 + T::TICK));
+        asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(v1) : "v"(lds0 + T::TICK));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         tk0 = (unsigned)__builtin_amdgcn_readfirstlane((int)v0);
@@ -296,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     // the bias loads are ordinary loads: touch their results here, so that the wait the compiler attaches to their first use
     // lands in the prologue and not inside the tile loop (where it would drain the patch DMA)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < T::NH; ++h)
 #pragma unroll
         for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bias_[h][e]));
     __builtin_amdgcn_s_barrier();
@@ -307,13 +333,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
     // time and leave the matrix pipe idle.  Waves 4-7 therefore DEFER the epilogue of a tile to the start of the next one
     // (accumulators parked in registers): their epilogue runs beside the K loop of waves 0-3 and vice versa.
     const bool defer = wave >= 4;
-    f32x4 pacc[2][4];
+    f32x4 pacc[2][T::NT];
     int p_img = 0, p_x0 = 0, p_y0 = 0, p_job = -1;        // p_job >= 0: the parked tile is the last of that job (statistics leave with it)
     bool have_prev = false;
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) pacc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T::NT; ++t) pacc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (;;) {
         // ---- the ticket of the job after next: thread 0 draws it at the start of this job (a returning atomic: 1-2 us; inline asm:
@@ -333,14 +359,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
             } else if (same) {
                 // inline asm: an LDS load the compiler can see would make it drain every outstanding store first
                 u32x4 v;
-                const uint32_t src = lds0 + SW_BYTES + cur * SP_BYTES + (STR * SPC) * 128 + tid * 16;
-                const uint32_t dstc = lds0 + SW_BYTES + (cur ^ 1) * SP_BYTES + tid * 16;
-                DSR128(v, src, 0);
-                LGKM_WAIT(0);
-                asm volatile("ds_write_b128 %0, %1" :: "v"(dstc), "v"(v) : "memory");
-                issue_patch(rs_in, dma_x, y0 + STR, SCARRY, cur ^ 1);
+                const uint32_t src = lds0 + T::W_BYTES + cur * T::P_BYTES + (STR * SPC) * T::PIXB + tid * 16;
+                const uint32_t dstc = lds0 + T::W_BYTES + (cur ^ 1) * T::P_BYTES + tid * 16;
+                if (CH == 64 || tid < 64 * T::PIXB / 16) {       // 64 pixels: 8 KB (every thread) / 4 KB (waves 0-3)
+                    DSR128(v, src, 0);
+                    LGKM_WAIT(0);
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(dstc), "v"(v) : "memory");
+                }
+                issue_patch(rs_in, dma_x, y0 + STR, T::CARRY, cur ^ 1);
             } else if (have_next) {
-                int img_n, x0_n, ty0_n, ty1_n, dma_n[6];
+                int img_n, x0_n, ty0_n, ty1_n, dma_n[T::NJ];
                 job_origin(njob, img_n, x0_n, ty0_n, ty1_n);
                 job_columns(x0_n, dma_n);
                 const __amdgpu_buffer_rsrc_t rs_n = image_rsrc(img_n);
@@ -349,43 +377,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
             int nst = 0;                                    // store instructions issued after the DMAs above
             if (defer && have_prev) {
                 nst = epilogue(pacc, p_img, p_x0, p_y0);
-                if (a.colstat && p_job >= 0) { flush_stats(p_job); nst += 8; }
+                if (a.colstat && p_job >= 0) { flush_stats(p_job); nst += 4 * T::NH; }
             }
-            // ---- K loop: 18 sub-steps, no synchronisation inside
-            f32x4 acc[2][4];
+            // ---- K loop: NU sub-steps, no synchronisation inside
+            f32x4 acc[2][T::NT];
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            uint32_t pa[6];
+                for (int t = 0; t < T::NT; ++t) acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint32_t pa[T::NG];
 #pragma unroll
-            for (int g = 0; g < 6; ++g) pa[g] = pbase[g / 3][g % 3] + cur * SP_BYTES;
-            u32x4 A[2][4], B[2][4];
+            for (int g = 0; g < T::NG; ++g) pa[g] = pbase[g / 3][g % 3] + cur * T::P_BYTES;
+            u32x4 A[2][T::NT], B[2][4];
             if (!UNETRIR_ABL(abl, 4)) {
-                issue_reads<0>(A, B, wa, wa8, pa);
-                k_substeps<0>(A, B, acc, wa, wa8, pa);
+                issue_reads<CH, 0>(A, B, wa, wa8, pa);
+                k_substeps<CH, 0>(A, B, acc, wa, wa8, pa);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (defer) {
 #pragma unroll
                 for (int o = 0; o < 2; ++o)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) pacc[o][t] = acc[o][t];
+                    for (int t = 0; t < T::NT; ++t) pacc[o][t] = acc[o][t];
                 p_img = img; p_x0 = x0; p_y0 = y0; p_job = same ? -1 : job; have_prev = true;
             } else {
                 nst = epilogue(acc, img, x0, y0);
-                if (a.colstat && !same) { flush_stats(job); nst += 8; }
+                if (a.colstat && !same) { flush_stats(job); nst += 4 * T::NH; }
             }
             // ---- the next patch is complete once this wave's DMAs are: they are older than the nst output stores, which may
             //      stay in flight across the barrier (so is thread 0's ticket)
+            //      (64 channels: 0 / 2 / 4 tile stores + 0 / 8 statistics stores; 32 channels: 0 / 1 / 2 + 0 / 4)
             if (nst == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if (nst == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else if (nst == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (nst == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (nst == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else if (nst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (nst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (nst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ty == ty0 && draw && tid == 0)
-                asm volatile("ds_write_b32 %0, %1" :: "v"(lds0 + STICK + 8 + 4 * par), "v"(tk_mine) : "memory");
+                asm volatile("ds_write_b32 %0, %1" :: "v"(lds0 + T::TICK + 8 + 4 * par), "v"(tk_mine) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -396,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
         have_next = false;
         if (draw) {                                       // the ticket drawn during the job just finished (behind >= 1 barrier)
             unsigned v;
-            asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds0 + STICK + 8 + 4 * par));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds0 + T::TICK + 8 + 4 * par));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
@@ -449,7 +481,8 @@ inline SPlan splan(const Conv3Args& a) {
 
 bool conv3x3s_applies(const Conv3Args& a) {
     const size_t img_bytes = (((size_t)a.H * a.W - 1) * a.ldi + a.C) * 2;
-    return unetrir_cfg().conv3x3s && a.C == 64 && a.N == 64 && !(a.flip & 2) && a.ldi >= 64 && (a.ldi & 7) == 0 && img_bytes < 0x70000000u;
+    return unetrir_cfg().conv3x3s && ((a.C == 64 && a.N == 64) || (a.C == 32 && a.N == 32)) && !(a.flip & 2) && a.ldi >= a.C && (a.ldi & 7) == 0 &&
+           img_bytes < 0x70000000u;
 }
 
 long long conv3x3s_colstat_rows(const Conv3Args& a) { return (long long)splan(a).njobs * 8; }      // one row per (job, wave)
@@ -457,7 +490,9 @@ long long conv3x3s_colstat_rows(const Conv3Args& a) { return (long long)splan(a)
 int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s) {
     const SPlan p = splan(a);
     unsigned* sched = p.grid == 256 ? sched_slot(s) : nullptr;          // tickets need workgroups on every XCD
-    hipLaunchKernelGGL(conv3x3s_bf16_kernel, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, (p.njobs + 7) / 8, sched,
-                       UNETRIR_ABL_HOST());
+    if (a.C == 64) hipLaunchKernelGGL(conv3x3s_bf16_kernel<64>, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, (p.njobs + 7) / 8, sched,
+                                      UNETRIR_ABL_HOST());
+    else hipLaunchKernelGGL(conv3x3s_bf16_kernel<32>, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, (p.njobs + 7) / 8, sched,
+                            UNETRIR_ABL_HOST());
     return (int)hipGetLastError();
 }
