@@ -25,7 +25,12 @@
 //     at once (a CU held by a collective or a side-stream kernel) leaves its jobs to the ones that run.
 // Patch LDS image: pixel-major, 128-byte pixels, the eight 16-byte granules of a pixel XOR-swizzled with (column & 7) on
 // the DMA source side and on the fragment read (conflict-free ds_read_b128 for 16 consecutive columns).
-// Requires C == 64 and N == 64 (conv3x3s_applies); everything else stays on conv3x3h / conv3x3g / conv3x3r.
+// Round 3: the same kernel for 32 -> 32 channels (template CH; the full-resolution layers of the residual graphs, dl_models/res_ae.py:466,
+// and of number_filters_0 = 32, main_training.py:154-161, which conv3x3h served with half of every MFMA tile empty and every pixel
+// line fetched in two pieces): 64-byte pixels, 16 per DMA instruction; two pixels share a 128-byte LDS line and the four granules of
+// a pixel are swizzled with (column >> 2) & 3, so that the 16 columns of a fragment read meet 16 different bank groups; one K chunk
+// (9 sub-steps of 4 MFMAs); 62 KB of LDS and 128 registers: two workgroups per CU.
+// Requires C == N == 64 or C == N == 32 (conv3x3s_applies); everything else stays on conv3x3h / conv3x3g / conv3x3r.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -124,7 +129,7 @@ __device__ __forceinline__ void k_substeps(u32x4 (&A)[2][SC<CH>::NT], u32x4 (&B)
 
 // abl (ablation build only): 1 no patch DMA after the first tile, 2 no output stores, 4 no MFMA loop
 template <int CH>
-__global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a, int nseg, int seglen, int per_xcd, unsigned* sched, int abl) {
+__global__ __launch_bounds__(512, CH == 32 ? 4 : 2) void conv3x3s_bf16_kernel(const Conv3Args a, int nseg, int seglen, int per_xcd, unsigned* sched, int abl) {
     using T = SC<CH>;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[T::SMEM + 16];
     const __bf16* __restrict__ in = (const __bf16*)a.in;
@@ -460,15 +465,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3s_bf16_kernel(const Conv3Args a
 
 namespace {
 struct SPlan { int grid, nseg, seglen, njobs; };
-// jobs = column strips x vertical segments; one persistent workgroup per CU.  Segments so that a workgroup serves >= 4 jobs: the
-// unit that tickets hand out (a workgroup placed late takes fewer), and imbalance <= 25 % where the strip count is no multiple
-// of the CU count.  A job's first tile fetches its two halo rows itself (10 instead of 8 patch rows: + 3 % at 8 tiles per job).
+// jobs = column strips x vertical segments; persistent workgroups.  Segments so that there are >= 1 024 jobs (four per workgroup at
+// 64 channels, two at 32): the unit that tickets hand out (a workgroup placed late takes fewer), and imbalance <= 25 % where the
+// strip count is no multiple of the CU count.  A job's first tile fetches its two halo rows itself (10 instead of 8 patch rows: + 3 % at 8 tiles per job).
 inline SPlan splan(const Conv3Args& a) {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + STR - 1) / STR;
     const long long nstrips = (long long)a.B * tiles_x;
-    const int cus = 256;
+    // 64 channels: 158 KB of LDS, one workgroup per CU; 32 channels: 62 KB and 128 registers, two per CU (measured at 128 x 128 / 256 x 256,
+    // batch 32: 28.5 / 75.7 us with 256 workgroups, 25.2 / 59.9 us with 512)
+    const int cus = a.C == 32 ? 512 : 256;
     int nseg = 1;
-    while (nseg < tiles_y && nstrips * nseg < 4LL * cus) ++nseg;
+    while (nseg < tiles_y && nstrips * nseg < 1024) ++nseg;
     SPlan p;
     p.seglen = (tiles_y + nseg - 1) / nseg;
     p.nseg = (tiles_y + p.seglen - 1) / p.seglen;
@@ -489,7 +496,7 @@ long long conv3x3s_colstat_rows(const Conv3Args& a) { return (long long)splan(a)
 
 int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s) {
     const SPlan p = splan(a);
-    unsigned* sched = p.grid == 256 ? sched_slot(s) : nullptr;          // tickets need workgroups on every XCD
+    unsigned* sched = (p.grid >= 256 && p.grid % 8 == 0) ? sched_slot(s) : nullptr;          // tickets need workgroups on every XCD
     if (a.C == 64) hipLaunchKernelGGL(conv3x3s_bf16_kernel<64>, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, (p.njobs + 7) / 8, sched,
                                       UNETRIR_ABL_HOST());
     else hipLaunchKernelGGL(conv3x3s_bf16_kernel<32>, dim3((unsigned)p.grid), dim3(512), 0, s, a, p.nseg, p.seglen, (p.njobs + 7) / 8, sched,
