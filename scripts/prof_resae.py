@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 import unet_rir_amd as U
+if "--lib" in sys.argv:      # another build of the library
+    U._lib.use_library(os.path.abspath(sys.argv[sys.argv.index("--lib") + 1]))
+    del sys.argv[sys.argv.index("--lib"):sys.argv.index("--lib") + 2]
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 10
 overlap = "--overlap" in sys.argv
