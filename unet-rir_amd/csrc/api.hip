@@ -74,7 +74,7 @@ extern "C" int unetrir_abl_hog(int n, long long cycles, int lds, void* sink, voi
 
 // ---- per-stream counter slots (kernels.h): static device arrays, one slot per (device, stream) in use.
 //      g_sched_slots: tile tickets of the persistent convolution kernels (64 group counters + 1 count of finished workgroups);
-//      g_sync_slots:  arrival counters of the kernels that finish a reduction in their last workgroup (gridsync.h).
+//      g_sync_slots:  arrival / barrier counters of the kernels that synchronise across workgroups (bnfused.hip).
 // Both are zero between launches: every kernel that uses a slot leaves it cleared.
 __device__ unsigned g_sched_slots[128][80];
 __device__ unsigned g_sync_slots[128][UNETRIR_SYNC_WORDS];

@@ -167,7 +167,7 @@ int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
 // than 128 streams are in use - the kernels then keep their fixed assignment.
 unsigned* sched_slot(hipStream_t s);
 // Arrival counters for kernels whose LAST workgroup (of the launch, or of one output tile) finishes a reduction the others fed
-// (gridsync.h): UNETRIR_SYNC_WORDS zero-initialised words per (device, stream); words [0, UNETRIR_SYNC_TILES) count arrivals per
+// (bnfused.hip): UNETRIR_SYNC_WORDS zero-initialised words per (device, stream); words [0, UNETRIR_SYNC_TILES) count arrivals per
 // output tile, word UNETRIR_SYNC_TILES counts arrivals of a whole launch.  nullptr when no slot is available (more than 128
 // streams in use, or first use inside a stream capture): the launchers then run the separate reduction kernel.
 #define UNETRIR_SYNC_TILES 512
