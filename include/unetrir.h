@@ -59,8 +59,11 @@ int unetrir_abi_version(void);
  *      specialised one that takes the shape; a switch set to 0 removes that kernel from the dispatch, so the layer runs on
  *      the next more general one - for A/B measurements and for parity cross-checks between kernels.  The switches are
  *      read ONCE, at first use, from the environment variables named below (the only variables the library reads) into
- *      this struct; unetrir_set_config replaces the values in effect (tests, A/B scripts: process-global, not
- *      thread-safe - call it while no launch is being issued).  Defaults: all 1 except bn_fused and igemm3.
+ *      an immutable snapshot of this struct; unetrir_set_config publishes a new snapshot atomically (tests, A/B scripts:
+ *      process-global; a launch issued concurrently on another thread sees the old values or the new ones, never a mixture
+ *      within one read - but a dispatch reads the switches more than once, so flip them between launches).  Defaults: all 1.
+ *      (Rounds 3's measured refusals - one-launch BatchNorm `bn_fused`, the LDS-DMA tap-table kernel `igemm3`, the head with
+ *      BatchNorm on its load path - were removed from the library in round 4; DESIGN.md keeps their numbers.)
  *        conv3x3        UNETRIR_CONV3X3        3x3 stride-1: patch-staged kernels at all (0: tap-table implicit GEMM)
  *        conv3x3g       UNETRIR_CONV3X3G       bf16 LDS-DMA kernel, > 64 output channels, and 64 output channels from > 64 input channels (64-channel tiles; conv3x3g.hip)
  *        conv3x3g_pair  UNETRIR_CONV3X3G_PAIR  its two-images-per-tile form for images <= 16 wide: 0 off, 1 when it yields
@@ -79,15 +82,10 @@ int unetrir_abi_version(void);
  *        upconv3x3q     UNETRIR_UPCONV3X3Q     bf16 persistent form of upconv3x3g for layers with >= 512 tiles (upconv3x3q.hip)
  *        dyn_tiles      UNETRIR_DYN_TILES      bf16 persistent kernels draw their tiles at run time (0: fixed assignment per workgroup)
  *        pw1x1          UNETRIR_PW1X1          bf16 register-streaming kernel of the 1x1 layers, forward and data gradient (pw1x1.hip)
- *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip)
- *        bn_fused       UNETRIR_BN_FUSED       its BatchNormalization passes of tensors <= 64 MB in one launch per direction (bnfused.hip: grid
- *                                              barriers).  DEFAULT 0: measured slower than the separate launches on MI355X (the numbers are in the file)
- *        igemm3         UNETRIR_IGEMM3         bf16 tap-table kernel with LDS-DMA staged K chunks (C % 64 == 0, > 64 output channels: igemm3_bf16.hip).
- *                                              DEFAULT 0: 5-17 % faster than the register-staged kernels launch by launch on warm caches, slower inside
- *                                              the train step (the numbers are in the file) */
+ *        igemm2         UNETRIR_IGEMM2         bf16 tap-table kernel for small problems: 64-pixel tiles, two K chunks in flight (igemm2_bf16.hip) */
 typedef struct {
     int conv3x3, conv3x3g, conv3x3g_pair, conv3x3h, conv3x3s, conv3x3r, stem, upconv3x3g, wgrad3x3g, wgrad3x3r, head_mfma,
-        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2, bn_fused, igemm3;
+        wgrad3x3d, conv3x3d, conv3x3p, upconv3x3q, dyn_tiles, pw1x1, igemm2;
 } unetrir_config;
 int unetrir_get_config(unetrir_config* out);
 int unetrir_set_config(const unetrir_config* in);
@@ -362,17 +360,6 @@ int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W
                              const float* bias, float* y, int ldy, unetrir_stream_t stream);
 int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy,
                                int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
-/* The head behind conv -> BatchNormalization -> ReLU (dl_models/u_net.py:241-248, :364-371): x is the PRE-BatchNorm tensor of the
- * last convolutional block and the kernels apply act(x * scale + shift) on their load path (affine = [scale C][shift C] as
- * unetrir_bn_stats_* / unetrir_bn_inference_affine write it; act 0 none, 1 ReLU, 2 LeakyReLU(0.3); same arithmetic and rounding
- * as unetrir_bn_apply_bf16 followed by the plain head: identical results) - the activation tensor of that block is never written
- * or read.  Padding pixels stay zero.  Supported where unetrir_head6x6_bn_supported(W, C) (C = 32 or 64, switch head_mfma on);
- * UNETRIR_EINVAL otherwise. */
-int unetrir_head6x6_bn_supported(int W, int C);
-int unetrir_head6x6_fwd_bn_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* affine, int act,
-                                const float* w, const float* bias, float* y, int ldy, unetrir_stream_t stream);
-int unetrir_head6x6_wgrad_bn_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* affine, int act,
-                                  const unetrir_bf16* dy, int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream);
 /* ---- fused column statistics (bf16).  The 3x3 stride-1 kernels that serve most layers can emit, per 16 x 32 pixel tile,
  *      the per-channel (sum, sum of squares) of the bf16 output they store: colstat is [rows][N][2] floats with N the
  *      convolution's output channels (forward: Cout, data gradient: Cin).  BatchNormalization statistics (dl_models/
@@ -408,9 +395,7 @@ int unetrir_bn_stats_colstat(const float* colstat, long long rows, long long P, 
                              unetrir_stream_t stream);
 int unetrir_colsum_colstat(const float* colstat, long long rows, int ldc, int c0, int C, float* out, unetrir_stream_t stream);
 /* unetrir_bn_stats_colstat followed by unetrir_bn_act_add_* in one call: statistics rows -> affine / saved / moving statistics, then
- * y = act(x * scale + shift (+ addend)): the finalize and the apply launch.  With the switch bn_fused = 1 tensors of at most 64 MB
- * run as ONE launch (the statistics are finished by the workgroups themselves, a grid barrier separates the phases; likewise
- * unetrir_bn_bwd_* / unetrir_bn_bwd_junction_*: reduce, finalize, apply in one launch) - measured slower, off by default. */
+ * y = act(x * scale + shift (+ addend)): the finalize and the apply launch. */
 int unetrir_bn_colstat_act_add_f32(const float* colstat, long long rows, const float* x, int ldx, long long P, int C, const float* gamma,
                                    const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* affine,
                                    float* saved, int act, const float* addend, int ldadd, float* y, int ldy, unetrir_stream_t stream);

@@ -29,7 +29,7 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-_DEFAULT_OFF = ("bn_fused", "igemm3")      # include/unetrir.h: every switch defaults to 1 except these
+_DEFAULT_OFF = ()      # include/unetrir.h: every switch defaults to 1
 
 
 @pytest.fixture(autouse=True)

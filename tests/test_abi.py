@@ -65,11 +65,11 @@ def test_library_reads_only_the_documented_environment_switches():
     found = sorted(set(re.findall(r"UNETRIR_[A-Z0-9_]+", out)))
     hdr = open(os.path.join(ROOT, "include", "unetrir.h")).read()
     documented = sorted(set(re.findall(r"(UNETRIR_[A-Z0-9_]+)\s+(?:3x3|bf16|its)", hdr)))
-    assert len(documented) == 20, documented
+    assert len(documented) == 18, documented
     assert found == documented, (found, documented)
     assert "unetrir_abl_set" not in out
     cfg = unet_rir_amd.ops.get_config()
     assert sorted(cfg) == sorted(n for n, _ in unet_rir_amd._lib.Config._fields_)
-    assert all(v == (0 if n in ("bn_fused", "igemm3") else 1) for n, v in cfg.items())          # measured refusals kept behind their switches
+    assert all(v == 1 for v in cfg.values())          # measured refusals are not shipped behind switches: they are removed
     old = unet_rir_amd.ops.set_config(conv3x3s=0)
     assert old["conv3x3s"] == 1 and unet_rir_amd.ops.get_config()["conv3x3s"] == 0

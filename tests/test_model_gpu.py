@@ -505,30 +505,8 @@ def test_inference_on_moving_statistics_and_save_load(U, tmp_path):
     assert torch.equal(m2.predict_stft([x.permute(0, 2, 3, 1), e]), got)
 
 
-def test_head_with_batchnorm_on_its_load_path_is_the_same_step(U):
-    """UNetEngine.head_bn (the head kernels read the pre-BatchNorm tensor of the last convolutional block, dl_models/u_net.py:241-248,
-    and apply BatchNorm + ReLU themselves; kept behind the flag because it measured slower): prediction, loss and every gradient are
-    IDENTICAL to the ordinary schedule, in training and with the moving statistics; the activation it skips is available on request."""
-    H, W, F0, B = 32, 48, 32, 2
-    gen = torch.Generator(); gen.manual_seed(5)
-    spec_in, spec_out = torch.rand((B, 2, H, W), generator=gen).to(DEV), torch.rand((B, 2, H, W), generator=gen).to(DEV)
-    emb = torch.randint(26, 1282, (B, 2, 16), generator=gen).to(DEV)
-    out = {}
-    for on in (False, True):
-        eng = U.UNetEngine(H, W, B, F0=F0, k=3, device=DEV, dtype="bf16")
-        g = torch.Generator(); g.manual_seed(0)
-        eng.reset_parameters(g)
-        assert eng.head_bn_supported and eng.head_bn is False
-        eng.head_bn = on
-        eng.training = True
-        eng.forward(spec_in, emb, target=spec_out, global_batch=B)
-        eng.backward()
-        torch.cuda.synchronize()
-        cur = dict(pred=eng.pred.clone(), loss=eng.loss_out.clone(), grad=eng.grad.clone(), top=eng.head_input().base.clone())
-        eng.training = False
-        eng.forward(spec_in, emb)
-        torch.cuda.synchronize()
-        cur["pred_eval"] = eng.pred.clone()
-        out[on] = cur
-    for k in out[True]:
-        assert torch.equal(out[True][k], out[False][k]), k
+def test_unknown_optimizer_name_is_refused(U):
+    """main_training.py:164-169 selects Nadam / SGD / Adam by name; anything else is an error here, not a silent default."""
+    eng = U.UNetEngine(32, 48, 2, F0=32, k=3, device=DEV, dtype="bf16")
+    with pytest.raises(ValueError):
+        U.Trainer(eng, optimizer="lamb")

@@ -266,7 +266,19 @@ def _dropout_worker(rank, world, port, out_path):
         tr2 = U.Trainer(eng, lr=1e-3, world_size=world, dropout=True)          # a second trainer over the same engine must not offset again
         m0 = eng.make_dropout_mask().clone()
         m1 = eng.make_dropout_mask().clone()
-        torch.save({"base": base, "seed": eng.dropout_seed, "m0": m0, "m1": m1, "step": eng._shared["dropout_step"]}, f"{out_path}.{rank}")
+        # resume: rank 0 writes ONE checkpoint, every rank restores it (trainer.CheckpointManager) - each replica must come back on
+        # ITS stream (base + rank), at the saved position
+        mgr = U.CheckpointManager(tr, out_path + ".ckpt")
+        if rank == 0:
+            mgr.save(epoch=0)
+        dist.barrier()
+        eng.dropout_seed = 0                          # whatever it was: the checkpoint decides
+        eng._shared["dropout_step"] = 99
+        mgr.restore()
+        seed_r, step_r = eng.dropout_seed, eng._shared["dropout_step"]
+        m2 = eng.make_dropout_mask().clone()
+        torch.save({"base": base, "seed": eng.dropout_seed, "m0": m0, "m1": m1, "step": 2, "seed_r": seed_r, "step_r": step_r, "m2": m2},
+                   f"{out_path}.{rank}")
         mpatch.undo()
         del tr, tr2
     finally:
@@ -286,6 +298,9 @@ def test_replicas_draw_independent_dropout_masks(tmp_path):
     assert not torch.equal(r0["m0"], r1["m0"]) and not torch.equal(r0["m0"], r0["m1"])
     assert r0["step"] == r1["step"] == 2
     assert abs(float((r0["m0"] > 0).float().mean()) - 0.7) < 0.1
+    # after every rank restored rank 0's checkpoint: own stream again (base + rank), saved position, masks differ across replicas
+    assert r0["seed_r"] == r0["base"] and r1["seed_r"] == r0["base"] + 1 and r0["step_r"] == r1["step_r"] == 2
+    assert not torch.equal(r0["m2"], r1["m2"]) and not torch.equal(r0["m2"], r0["m1"])
 
 
 @pytest.mark.parametrize("opt", ["sgd", "nadam"])

@@ -22,7 +22,7 @@ class CastDesc(C.Structure):
 class Config(C.Structure):
     """unetrir_config: kernel-selection switches (include/unetrir.h)."""
     _fields_ = [(n, C.c_int) for n in ("conv3x3", "conv3x3g", "conv3x3g_pair", "conv3x3h", "conv3x3s", "conv3x3r", "stem",
-                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d", "conv3x3p", "upconv3x3q", "dyn_tiles", "pw1x1", "igemm2", "bn_fused", "igemm3")]
+                                       "upconv3x3g", "wgrad3x3g", "wgrad3x3r", "head_mfma", "wgrad3x3d", "conv3x3d", "conv3x3p", "upconv3x3q", "dyn_tiles", "pw1x1", "igemm2")]
 
 
 class ConvGeom(C.Structure):
@@ -126,11 +126,6 @@ _SIGS = {
                                            C.c_int, c_stream]),
     "unetrir_head6x6_wgrad_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int,
                                              c_f32p, C.c_void_p, C.c_size_t, c_stream]),
-    "unetrir_head6x6_bn_supported": (C.c_int, [C.c_int, C.c_int]),
-    "unetrir_head6x6_fwd_bn_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
-                                              C.c_int, c_stream]),
-    "unetrir_head6x6_wgrad_bn_bf16": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
-                                                c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_stage_h2d": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), c_stream]),
     "unetrir_conv2d_colstat_rows_bf16": (C.c_longlong, [C.POINTER(ConvGeom), C.c_int, C.c_int]),
     "unetrir_conv3x3_kernel_id_bf16": (C.c_int, [C.POINTER(ConvGeom), C.c_int, C.c_int]),

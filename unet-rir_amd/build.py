@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libunetrir.so")
-SOURCES = ["igemm.hip", "api.hip", "elementwise.hip", "head.hip", "head_mfma.hip", "wgrad3x3.hip", "wgrad3x3r.hip", "wgrad3x3g.hip", "wgrad3x3d.hip", "igemm_bf16.hip", "conv3x3.hip", "conv3x3r.hip", "conv3x3g.hip", "conv3x3h.hip", "conv3x3s.hip", "conv3x3d.hip", "conv3x3p.hip", "upconv3x3.hip", "upconv3x3g.hip", "upconv3x3q.hip", "features.hip", "dense.hip", "stem3x3.hip", "pw1x1.hip", "igemm2_bf16.hip", "bnfused.hip", "igemm3_bf16.hip"]
+SOURCES = ["igemm.hip", "api.hip", "elementwise.hip", "head.hip", "head_mfma.hip", "wgrad3x3.hip", "wgrad3x3r.hip", "wgrad3x3g.hip", "wgrad3x3d.hip", "igemm_bf16.hip", "conv3x3.hip", "conv3x3r.hip", "conv3x3g.hip", "conv3x3h.hip", "conv3x3s.hip", "conv3x3d.hip", "conv3x3p.hip", "upconv3x3.hip", "upconv3x3g.hip", "upconv3x3q.hip", "features.hip", "dense.hip", "stem3x3.hip", "pw1x1.hip", "igemm2_bf16.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

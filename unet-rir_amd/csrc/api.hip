@@ -2,54 +2,57 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "kernels.h"
 
-// ---- kernel-selection switches: the only environment variables the library reads, once, into one struct ----
+// ---- kernel-selection switches: the only environment variables the library reads, once.  The switches in effect are an IMMUTABLE
+//      snapshot behind one atomic pointer: unetrir_set_config publishes a new snapshot (release), every reader takes the pointer
+//      (acquire) - a launch being issued on another thread sees the old values or the new ones, never a half-written struct.
+//      Replaced snapshots are kept (a few hundred bytes per call of a function only tests and A/B scripts use): a reader may still
+//      hold one.
 namespace {
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-unetrir_config load_config() {
-    unetrir_config c;
-    c.conv3x3 = env_int("UNETRIR_CONV3X3", 1);
-    c.conv3x3g = env_int("UNETRIR_CONV3X3G", 1);
-    c.conv3x3g_pair = env_int("UNETRIR_CONV3X3G_PAIR", 1);
-    c.conv3x3h = env_int("UNETRIR_CONV3X3H", 1);
-    c.conv3x3s = env_int("UNETRIR_CONV3X3S", 1);
-    c.conv3x3r = env_int("UNETRIR_CONV3X3R", 1);
-    c.stem = env_int("UNETRIR_STEM", 1);
-    c.upconv3x3g = env_int("UNETRIR_UPCONV3X3G", 1);
-    c.wgrad3x3g = env_int("UNETRIR_WGRAD3X3G", 1);
-    c.wgrad3x3r = env_int("UNETRIR_WGRAD3X3R", 1);
-    c.wgrad3x3d = env_int("UNETRIR_WGRAD3X3D", 1);
-    c.conv3x3d = env_int("UNETRIR_CONV3X3D", 1);
-    c.conv3x3p = env_int("UNETRIR_CONV3X3P", 1);
-    c.upconv3x3q = env_int("UNETRIR_UPCONV3X3Q", 1);
-    c.dyn_tiles = env_int("UNETRIR_DYN_TILES", 1);
-    c.head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
-    c.pw1x1 = env_int("UNETRIR_PW1X1", 1);
-    c.igemm2 = env_int("UNETRIR_IGEMM2", 1);
-    c.igemm3 = env_int("UNETRIR_IGEMM3", 0);
-    c.bn_fused = env_int("UNETRIR_BN_FUSED", 0);          // measured slower than the separate launches (bnfused.hip): off unless asked for
+const unetrir_config* load_config() {
+    unetrir_config* c = new unetrir_config;
+    c->conv3x3 = env_int("UNETRIR_CONV3X3", 1);
+    c->conv3x3g = env_int("UNETRIR_CONV3X3G", 1);
+    c->conv3x3g_pair = env_int("UNETRIR_CONV3X3G_PAIR", 1);
+    c->conv3x3h = env_int("UNETRIR_CONV3X3H", 1);
+    c->conv3x3s = env_int("UNETRIR_CONV3X3S", 1);
+    c->conv3x3r = env_int("UNETRIR_CONV3X3R", 1);
+    c->stem = env_int("UNETRIR_STEM", 1);
+    c->upconv3x3g = env_int("UNETRIR_UPCONV3X3G", 1);
+    c->wgrad3x3g = env_int("UNETRIR_WGRAD3X3G", 1);
+    c->wgrad3x3r = env_int("UNETRIR_WGRAD3X3R", 1);
+    c->wgrad3x3d = env_int("UNETRIR_WGRAD3X3D", 1);
+    c->conv3x3d = env_int("UNETRIR_CONV3X3D", 1);
+    c->conv3x3p = env_int("UNETRIR_CONV3X3P", 1);
+    c->upconv3x3q = env_int("UNETRIR_UPCONV3X3Q", 1);
+    c->dyn_tiles = env_int("UNETRIR_DYN_TILES", 1);
+    c->head_mfma = env_int("UNETRIR_HEAD_MFMA", 1);
+    c->pw1x1 = env_int("UNETRIR_PW1X1", 1);
+    c->igemm2 = env_int("UNETRIR_IGEMM2", 1);
     return c;
 }
-unetrir_config& config_storage() {
-    static unetrir_config c = load_config();
-    return c;
+std::atomic<const unetrir_config*>& config_slot() {
+    static std::atomic<const unetrir_config*> p{load_config()};
+    return p;
 }
 }  // namespace
-const unetrir_config& unetrir_cfg() { return config_storage(); }
+const unetrir_config& unetrir_cfg() { return *config_slot().load(std::memory_order_acquire); }
 extern "C" int unetrir_get_config(unetrir_config* out) {
     if (!out) return UNETRIR_EINVAL;
-    *out = config_storage();
+    *out = unetrir_cfg();
     return 0;
 }
 extern "C" int unetrir_set_config(const unetrir_config* in) {
     if (!in) return UNETRIR_EINVAL;
-    config_storage() = *in;
+    config_slot().store(new unetrir_config(*in), std::memory_order_release);
     return 0;
 }
 
@@ -72,69 +75,68 @@ extern "C" int unetrir_abl_hog(int n, long long cycles, int lds, void* sink, voi
 }
 #endif
 
-// ---- per-stream counter slots (kernels.h): static device arrays, one slot per (device, stream) in use.
-//      g_sched_slots: tile tickets of the persistent convolution kernels (64 group counters + 1 count of finished workgroups);
-//      g_sync_slots:  arrival / barrier counters of the kernels that synchronise across workgroups (bnfused.hip).
-// Both are zero between launches: every kernel that uses a slot leaves it cleared.
+// ---- per-stream ticket slots (kernels.h): a static device array, one slot per (device, stream) in use: the tile tickets of the
+//      persistent convolution kernels (64 group counters + 1 count of finished workgroups).  Zero between launches: every kernel
+//      that uses a slot leaves it cleared.
 __device__ unsigned g_sched_slots[128][80];
-__device__ unsigned g_sync_slots[128][UNETRIR_SYNC_WORDS];
 // A __device__ symbol has one instance PER DEVICE: the table below is keyed by the device that is current at the launch (the
 // reference's own process shape is one process driving several GPUs, main_training.py:56), and a slot by (device, stream).
 // More than 16 devices or 128 streams in use on one device: no slot (-1) - the callers then take their slot-free path.
+// The table is append-only, so the lookup every persistent-kernel launch performs takes NO lock: `used` is published with release
+// after the owner entry is written; only a miss (a stream's first launch, a device's first use) takes the mutex.
 namespace {
-struct SlotTable { unsigned* sched = nullptr; unsigned* sync = nullptr; hipStream_t owner[128]; int used = 0; };
+struct SlotTable { std::atomic<unsigned*> sched{nullptr}; hipStream_t owner[128]; std::atomic<int> used{0}; };
 constexpr int MAX_DEV = 16;
 std::mutex g_slot_mu;
 SlotTable g_slot_tab[MAX_DEV];
 
-// index of the slot of (current device, s), or -1; *tab receives the device's table
-int slot_index(hipStream_t s, SlotTable** tab) {
+// index of the slot of (current device, s), or -1; *base receives the device's slot array
+int slot_index(hipStream_t s, unsigned** base) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return -1;
-    std::lock_guard<std::mutex> lk(g_slot_mu);
     SlotTable& d = g_slot_tab[dev];
-    if (!d.sched) {
-        void *p = nullptr, *q = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess ||
-            hipGetSymbolAddress(&q, HIP_SYMBOL(g_sync_slots)) != hipSuccess) return -1;              // resolve on the current device
+    unsigned* sched = d.sched.load(std::memory_order_acquire);
+    if (sched) {
+        const int n = d.used.load(std::memory_order_acquire);
+        for (int i = 0; i < n; ++i) if (d.owner[i] == s) { *base = sched; return i; }
+    }
+    std::lock_guard<std::mutex> lk(g_slot_mu);           // miss: first launch of this stream (or first use of this device)
+    sched = d.sched.load(std::memory_order_relaxed);
+    if (!sched) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return -1;              // resolve on the current device
         // zeroed once, synchronously, on first use of this device (a stream that is being captured into a HIP graph refuses the
         // call: no slot then, and nothing is cached - the engines call unetrir_reset_tile_tickets() when they are built)
-        if (hipMemset(p, 0, sizeof(unsigned) * 128 * 80) != hipSuccess || hipMemset(q, 0, sizeof(unsigned) * 128 * UNETRIR_SYNC_WORDS) != hipSuccess) {
+        if (hipMemset(p, 0, sizeof(unsigned) * 128 * 80) != hipSuccess) {
             (void)hipGetLastError();
             return -1;
         }
-        d.sched = (unsigned*)p; d.sync = (unsigned*)q;
+        sched = (unsigned*)p;
+        d.sched.store(sched, std::memory_order_release);
     }
-    *tab = &d;
-    for (int i = 0; i < d.used; ++i) if (d.owner[i] == s) return i;
-    if (d.used == 128) return -1;
-    d.owner[d.used] = s;
-    return d.used++;
+    *base = sched;
+    const int n = d.used.load(std::memory_order_relaxed);
+    for (int i = 0; i < n; ++i) if (d.owner[i] == s) return i;      // another thread appended it meanwhile
+    if (n == 128) return -1;
+    d.owner[n] = s;
+    d.used.store(n + 1, std::memory_order_release);
+    return n;
 }
 }  // namespace
 
 unsigned* sched_slot(hipStream_t s) {
     if (!unetrir_cfg().dyn_tiles) return nullptr;
-    SlotTable* t = nullptr;
-    const int i = slot_index(s, &t);
-    return i < 0 ? nullptr : t->sched + i * 80;
-}
-
-unsigned* sync_slot(hipStream_t s) {
-    SlotTable* t = nullptr;
-    const int i = slot_index(s, &t);
-    return i < 0 ? nullptr : t->sync + (size_t)i * UNETRIR_SYNC_WORDS;
+    unsigned* base = nullptr;
+    const int i = slot_index(s, &base);
+    return i < 0 ? nullptr : base + i * 80;
 }
 
 // Host-side reset of every ticket slot of the current device (after toggling dyn_tiles, or after a launch failed): call with the
 // device idle.  The kernels clear their own slot at the end of every launch, so a healthy run never needs it.
 extern "C" int unetrir_reset_tile_tickets(void) {
-    void *p = nullptr, *q = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess || hipGetSymbolAddress(&q, HIP_SYMBOL(g_sync_slots)) != hipSuccess)
-        return UNETRIR_EINVAL;
-    const hipError_t e = hipMemset(p, 0, sizeof(unsigned) * 128 * 80);
-    if (e != hipSuccess) return (int)e;
-    return (int)hipMemset(q, 0, sizeof(unsigned) * 128 * UNETRIR_SYNC_WORDS);
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sched_slots)) != hipSuccess) return UNETRIR_EINVAL;
+    return (int)hipMemset(p, 0, sizeof(unsigned) * 128 * 80);
 }
 
 namespace {

@@ -737,11 +737,6 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !chan_ok(da, ldda, P, C, VecOf<T>::N) || !dx || lddx < C || lddx % VecOf<T>::N || !affine || !saved || !ws ||
         ws_bytes < unetrir_bn_ws_bytes(P, C))
         return UNETRIR_EINVAL;
-    if (bn_fused_applies(P, C, (int)sizeof(T))) {        // small tensors: reduce, finalize and apply in one launch (bnfused.hip)
-        const int e = launch_bn_bwd_fused(sizeof(T) == 2, da, ldda, x, ldx, nullptr, 0, P, C, affine, saved, relu, dx, lddx, nullptr, 0, nullptr, 0,
-                                          dgamma, dbeta, ws, ws_bytes, s);
-        if (e != BN_FUSED_NOT_TAKEN) return e;
-    }
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
@@ -763,11 +758,6 @@ int bn_bwd_junction_impl(const T* da, int ldda, const T* x, int ldx, const T* ou
         !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C) || act < 0 || act > 2 || (gskip && (ldgs < C || ldgs % V)) ||
         (gskip_add && (!gskip || ldga < C || ldga % V)))
         return UNETRIR_EINVAL;
-    if (bn_fused_applies(P, C, (int)sizeof(T))) {
-        const int e = launch_bn_bwd_fused(sizeof(T) == 2, da, ldda, x, ldx, out, ldo, P, C, affine, saved, act, dx, lddx, gskip, ldgs, gskip_add,
-                                          ldga, dgamma, dbeta, ws, ws_bytes, s);
-        if (e != BN_FUSED_NOT_TAKEN) return e;
-    }
     const ChanPlan pl = chan_plan(P, C, V);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
@@ -820,7 +810,6 @@ size_t unetrir_bn_ws_bytes(long long P, int C) {
     if (P <= 0 || C <= 0) return 0;
     const ChanPlan pl = chan_plan(P, C);
     size_t b = ((size_t)pl.nslab * C * 2) * sizeof(double) + (size_t)2 * C * sizeof(float);
-    if (bn_fused_applies(P, C, 2) || bn_fused_applies(P, C, 4)) { const size_t f = bn_fused_ws_bytes(C); if (f > b) b = f; }
     return b;
 }
 
@@ -1136,7 +1125,7 @@ int unetrir_cast_bf16_to_f32(const unetrir_bf16* a, float* y, long long n, unetr
 }  // extern "C"
 
 /* BatchNormalization forward from a convolution's column statistics in ONE call: statistics -> affine (+ moving statistics), then
- * y = act(x * scale + shift (+ addend)); small tensors in one launch (bnfused.hip), else the finalize and the apply launch. */
+ * y = act(x * scale + shift (+ addend)): the finalize and the apply launch. */
 template <typename T>
 static int bn_colstat_act_add_impl(const float* colstat, long long rows, const T* x, int ldx, long long P, int C, const float* gamma,
                                    const float* beta, float eps, float momentum, float* mm, float* mv, float* affine, float* saved, int act,
@@ -1145,11 +1134,6 @@ static int bn_colstat_act_add_impl(const float* colstat, long long rows, const T
     if (!colstat || rows <= 0 || rows > 0x7fffffffLL || !chan_ok(x, ldx, P, C, V) || !affine || !saved || !y || ldy < C || ldy % V || act < 0 ||
         act > 2 || (addend && (ldadd < C || ldadd % V)))
         return UNETRIR_EINVAL;
-    if (bn_fused_applies(P, C, (int)sizeof(T))) {
-        const int e = launch_bn_fwd_fused(sizeof(T) == 2, colstat, rows, x, ldx, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved, act, addend,
-                                          ldadd, y, ldy, s);
-        if (e != BN_FUSED_NOT_TAKEN) return e;
-    }
     hipLaunchKernelGGL(bn_finalize_kernel<float>, fin_grid(C), dim3(FIN_T), 0, s, colstat, (int)rows, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved);
     hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, x, ldx, P, C, (const float*)affine, act, y, ldy, addend, ldadd);
     return (int)hipGetLastError();
@@ -1235,7 +1219,8 @@ __global__ void step_advance_kernel(unsigned long long* __restrict__ state, cons
     const unsigned long long t = state[0] + (advance_t ? 1ull : 0ull);      // advance_t == 0: a forward-only pass (validation) draws masks too
     state[0] = t;
     const double b1 = (double)cfg[1], b2 = (double)cfg[2];
-    hyper[0] = (float)((double)cfg[0] * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
+    // t == 0 (a forward-only pass on a fresh engine): no optimizer step can follow, and 0 / 0 must not reach hyper[0]
+    hyper[0] = t == 0 ? 0.f : (float)((double)cfg[0] * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
     hyper[1] = cfg[1]; hyper[2] = cfg[2]; hyper[3] = cfg[3]; hyper[4] = cfg[4];
     const unsigned long long d = state[1];
     state[2] = d;

@@ -152,19 +152,13 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x
 namespace {
 
 template <typename T>
-int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s,
-                  const float* affine = nullptr, int act = 0) {
+int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || ldy < 2 || (ldy >= 4 && (ldy & 3)))
         return UNETRIR_EINVAL;
     if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip; images wider than 256 pixels in column blocks)
         const bool mfma = unetrir_cfg().head_mfma != 0;
-        if (affine) {                    // BatchNorm + activation on the load path: the matrix-core kernels only
-            if (!mfma || !head_mfma_bn_applies(W, C) || (ldx & 7) || act < 0 || act > 2) return UNETRIR_EINVAL;
-            return launch_head_fwd_mfma(x, ldx, B, H, W, C, w, bias, y, ldy, s, affine, act);
-        }
         if (mfma && head_mfma_applies(W, C) && (ldx & 7) == 0) return launch_head_fwd_mfma(x, ldx, B, H, W, C, w, bias, y, ldy, s);
     }
-    if (affine) return UNETRIR_EINVAL;
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
     if (C % 32 == 0) hipLaunchKernelGGL((head_fwd_kernel<32, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
     else if (C % 16 == 0) hipLaunchKernelGGL((head_fwd_kernel<16, T>), dim3((unsigned)tiles), dim3(256), 0, s, x, ldx, B, H, W, C, w, bias, y, ldy);
@@ -174,21 +168,19 @@ int head_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, const float* 
 
 template <typename T>
 int head_wgrad_impl(const T* x, int ldx, int B, int H, int W, int C, const T* dy, int lddy, float* dw, void* ws, size_t ws_bytes,
-                    hipStream_t s, const float* affine = nullptr, int act = 0) {
+                    hipStream_t s) {
     if (!x || !dy || !dw || !ws || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || ldx < C || (ldx & 3) || lddy < 2 || (lddy & 1) ||
         ws_bytes < (size_t)HEAD_WGRAD_BLOCKS * 2 * HK * HK * C * sizeof(float))
         return UNETRIR_EINVAL;
     if constexpr (sizeof(T) == 2) {      // bf16: matrix-core path (head_mfma.hip)
         const bool mfma = unetrir_cfg().head_mfma != 0;
-        if (affine && (!mfma || !head_mfma_bn_applies(W, C) || (ldx & 7) || act < 0 || act > 2)) return UNETRIR_EINVAL;
         if (mfma && W <= 4096 && C % 32 == 0 && (ldx & 7) == 0) {
             int nb = 0;
-            const int err = launch_head_wgrad_mfma(x, ldx, B, H, W, C, dy, lddy, (float*)ws, HEAD_WGRAD_BLOCKS, &nb, s, affine, act);
+            const int err = launch_head_wgrad_mfma(x, ldx, B, H, W, C, dy, lddy, (float*)ws, HEAD_WGRAD_BLOCKS, &nb, s);
             if (err) return err;
             return launch_splitk_reduce((const float*)ws, nb, (size_t)2 * HK * HK * C, dw, 0.f, nullptr, s);
         }
     }
-    if (affine) return UNETRIR_EINVAL;
     const long long tiles = (long long)B * ((H + HT - 1) / HT) * ((W + HT - 1) / HT);
     const int nblk = tiles < HEAD_WGRAD_BLOCKS ? (int)tiles : HEAD_WGRAD_BLOCKS;
     if (C % 32 == 0)
@@ -228,21 +220,6 @@ int unetrir_head6x6_fwd_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W
 int unetrir_head6x6_wgrad_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const unetrir_bf16* dy, int lddy,
                                float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
     return head_wgrad_impl<__bf16>((const __bf16*)x, ldx, B, H, W, C, (const __bf16*)dy, lddy, dw, ws, ws_bytes, (hipStream_t)stream);
-}
-
-/* the head behind conv -> BatchNormalization -> activation (dl_models/u_net.py:241-248): x is the PRE-BatchNorm tensor */
-int unetrir_head6x6_bn_supported(int W, int C) { return (unetrir_cfg().head_mfma && head_mfma_bn_applies(W, C)) ? 1 : 0; }
-
-int unetrir_head6x6_fwd_bn_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* affine, int act, const float* w,
-                                const float* bias, float* y, int ldy, unetrir_stream_t stream) {
-    if (!affine) return UNETRIR_EINVAL;
-    return head_fwd_impl<__bf16>((const __bf16*)x, ldx, B, H, W, C, w, bias, y, ldy, (hipStream_t)stream, affine, act);
-}
-
-int unetrir_head6x6_wgrad_bn_bf16(const unetrir_bf16* x, int ldx, int B, int H, int W, int C, const float* affine, int act,
-                                  const unetrir_bf16* dy, int lddy, float* dw, void* ws, size_t ws_bytes, unetrir_stream_t stream) {
-    if (!affine) return UNETRIR_EINVAL;
-    return head_wgrad_impl<__bf16>((const __bf16*)x, ldx, B, H, W, C, (const __bf16*)dy, lddy, dw, ws, ws_bytes, (hipStream_t)stream, affine, act);
 }
 
 int unetrir_head6x6_dgrad_supported(int W, int C) { return head_dgrad_mfma_applies(W, C) ? 1 : 0; }

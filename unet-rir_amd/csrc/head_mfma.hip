@@ -22,15 +22,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Images wider than 256 pixels (configs[3]: 512) are cut into ncb column blocks of owb <= 250 OUTPUT columns: a workgroup still
 // holds 256 columns of S, those of the input columns g0 .. g0 + 255 with g0 = cb * owb - 2, i.e. its output columns plus the two
 // columns to the left and the three to the right that their horizontal taps reach (S of a column depends on that input column only).
-// BN (template): x is the PRE-BatchNorm tensor of the layer in front of the head and the kernel applies act(x * scale + shift) on
-// its load path (affine = [scale C][shift C], the arithmetic and rounding of bn_apply_kernel, elementwise.hip) - the activation
-// tensor is never written or read: one 2 x 268 MB pass less per step at configs[1].  Pixels outside the image stay zero (the
-// padding of the convolution applies to the ACTIVATION).
-template <int NCH, bool BN>
+// (Round 3 built a variant with BatchNormalization + ReLU of the layer in front of the head on this kernel's load path - the
+// activation tensor never written: identical results, head forward 80 -> 133 us, weight gradient 106 -> 164 us against the 105 us
+// BatchNorm-apply pass it removed.  Measured slower, removed in round 4; DESIGN.md section 8 item 4 keeps the numbers.)
+template <int NCH>
 __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ y, int ldy, int ncb, int owb,
-                                                             const float* __restrict__ affine, int act) {
+                                                             float* __restrict__ y, int ldy, int ncb, int owb) {
     constexpr int C = 32 * NCH;
     __shared__ __attribute__((aligned(16))) float S[2][256][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,14 +63,6 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
     // x fragments (B operand): column = pixel q, k = 8 channels; two 16-pixel tiles per wave
     const int q0 = wave * 32 + l15;
     const __bf16* xb = x + (size_t)img * H * W * ldx + lq * 8;
-    float sc[BN ? NCH : 1][8], sh[BN ? NCH : 1][8];      // this lane's channels: 32 ch + 8 lq + e
-    if constexpr (BN) {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { sc[ch][e] = affine[ch * 32 + lq * 8 + e]; sh[ch][e] = affine[C + ch * 32 + lq * 8 + e]; }
-    }
-    const float sl = act == 2 ? 0.3f : 0.f;
     auto load_row = [&](int iy, bf16x8 (&f)[2][NCH]) {
         const bool rok = (unsigned)iy < (unsigned)H;
 #pragma unroll
@@ -85,26 +75,6 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
                 for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
                 if (rok && (unsigned)q < (unsigned)W) v = *reinterpret_cast<const bf16x8*>(xb + ((size_t)iy * W + q) * ldx + ch * 32);
                 f[t][ch] = v;
-            }
-        }
-    };
-
-    // BN: applied where a row's fragments are USED (a step after their loads were issued: at load time the wait for the data would
-    // stand in front of the previous row's matrix work); columns outside the image keep their zeros
-    auto bn_row = [&](bf16x8 (&f)[2][NCH]) {
-        if constexpr (BN) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (!((unsigned)(g0 + q0 + 16 * t) < (unsigned)W)) continue;
-#pragma unroll
-                for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float r = (float)f[t][ch][e] * sc[ch][e] + sh[ch][e];
-                        if (act == 1) r = fmaxf(r, 0.f);
-                        else if (act) r = r > 0.f ? r : sl * r;
-                        f[t][ch][e] = (__bf16)r;
-                    }
             }
         }
     };
@@ -125,7 +95,6 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
         const int ii = i + U;                                                                                    \
         load_row(y0 - 2 + ii + 1, NXT);                                                                          \
         if ((unsigned)(y0 - 2 + ii) < (unsigned)H) {                                                             \
-            bn_row(CUR);                                                                                         \
             _Pragma("unroll") for (int kh = 0; kh < 6; ++kh) {                                                   \
                 const int orow = ii - kh;                                                                        \
                 if (orow < 0 || orow >= nrows) continue;                                                         \
@@ -167,24 +136,15 @@ __global__ __launch_bounds__(512) void head_fwd_mfma_kernel(const __bf16* __rest
 
 bool head_mfma_applies(int W, int C) { return W <= 4096 && (C == 32 || C == 64 || C == 128); }
 
-// BatchNorm on the load path: the per-lane scale / shift registers fit beside the kernel fragments up to 64 channels
-bool head_mfma_bn_applies(int W, int C) { return W <= 4096 && (C == 32 || C == 64); }
-
 int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy,
-                         hipStream_t s, const float* affine, int act) {
+                         hipStream_t s) {
     const int ncb = W <= 256 ? 1 : (W + 249) / 250;                  // column blocks of at most 250 output columns (+ 2 + 3 halo = 255 <= 256)
     const int owb = (W + ncb - 1) / ncb;
     const unsigned grid = (unsigned)(B * ((H + HM_ROWS - 1) / HM_ROWS) * ncb);
     const __bf16* xp = (const __bf16*)x;
-    if (affine) {
-        if (C == 32) hipLaunchKernelGGL((head_fwd_mfma_kernel<1, true>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb, affine, act);
-        else if (C == 64) hipLaunchKernelGGL((head_fwd_mfma_kernel<2, true>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb, affine, act);
-        else return UNETRIR_EINVAL;
-        return (int)hipGetLastError();
-    }
-    if (C == 32) hipLaunchKernelGGL((head_fwd_mfma_kernel<1, false>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb, affine, act);
-    else if (C == 64) hipLaunchKernelGGL((head_fwd_mfma_kernel<2, false>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb, affine, act);
-    else hipLaunchKernelGGL((head_fwd_mfma_kernel<4, false>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb, affine, act);
+    if (C == 32) hipLaunchKernelGGL((head_fwd_mfma_kernel<1>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb);
+    else if (C == 64) hipLaunchKernelGGL((head_fwd_mfma_kernel<2>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb);
+    else hipLaunchKernelGGL((head_fwd_mfma_kernel<4>), dim3(grid), dim3(512), 0, s, xp, ldx, B, H, W, w, bias, y, ldy, ncb, owb);
     return (int)hipGetLastError();
 }
 
@@ -203,10 +163,9 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_h;
 #define HW_DL 264             // D' (n,kw) stride, elements (528 B)
 #define HW_ROWS 16            // dy rows per workgroup step: 2 workgroups per CU x 256 CUs = 512 blocks for 32 x 256 rows
 
-template <bool BN>
 __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* __restrict__ x, int ldx, int B, int H, int W, int C,
                                                                  const __bf16* __restrict__ dy, int lddy,
-                                                                 float* __restrict__ part, const float* __restrict__ affine, int act) {
+                                                                 float* __restrict__ part) {
     // 78.2 KB of LDS: two workgroups per CU hide each other's row loads (one x row buffer; (n,kw) rows 12..15 are zero
     // fragments made in registers)
     __shared__ __attribute__((aligned(16))) __bf16 Xs[256 * HW_XL];         // 40960 B
@@ -226,15 +185,6 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 
     const int g8 = tid & 7, qsub = tid >> 3;          // x staging: 16-byte granule g8 of pixel qsub + 32*j
     uint4 rx[8];
-    float sc[BN ? 8 : 1], sh[BN ? 8 : 1];             // BN: x is the pre-BatchNorm tensor (head_fwd_mfma_kernel); this thread's 8 channels
-    if constexpr (BN) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c0 + g8 * 8 + e;
-            sc[e] = c < C ? affine[c] : 0.f; sh[e] = c < C ? affine[C + c] : 0.f;
-        }
-    }
-    const float sl = act == 2 ? 0.3f : 0.f;
     // images wider than 256 pixels: column blocks of 256 x columns (a partition - the sum over pixels needs no halo of x); the shifted
     // copies D' of a block reach three dy columns to its left and two to its right, which five threads load beside the block's own
     const int ncb = (W + 255) / 256;
@@ -275,23 +225,6 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
             const int iy = y0 - 2 + i;
             __syncthreads();                          // the previous step's MFMAs are done with the x row and with the ring
             __bf16* Xb = Xs;
-            if constexpr (BN) {       // applied where the row is used (its loads were issued a step ago); pixels outside the image keep their zeros
-                if ((unsigned)iy < (unsigned)H && c0 + g8 * 8 < C) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (!(g0 + qsub + 32 * j < W)) continue;
-                        bf16x8 h = __builtin_bit_cast(bf16x8, rx[j]);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float r = (float)h[e] * sc[e] + sh[e];
-                            if (act == 1) r = fmaxf(r, 0.f);
-                            else if (act) r = r > 0.f ? r : sl * r;
-                            h[e] = (__bf16)r;
-                        }
-                        rx[j] = __builtin_bit_cast(uint4, h);
-                    }
-                }
-            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(Xb + (qsub + 32 * j) * HW_XL + g8 * 8) = rx[j];
             const bool newdy = i < nrows;             // dy row y0 + i enters the ring (vertical tap kh = 0 of this x row)
@@ -361,14 +294,12 @@ __global__ __launch_bounds__(256, 2) void head_wgrad_mfma_kernel(const __bf16* _
 }
 
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
-                           int* nblk_out, hipStream_t s, const float* affine, int act) {
+                           int* nblk_out, hipStream_t s) {
     int nblk = B * ((H + HW_ROWS - 1) / HW_ROWS) * ((W + 255) / 256);
     if (nblk > max_blocks) nblk = max_blocks;
     *nblk_out = nblk;
-    if (affine) hipLaunchKernelGGL(head_wgrad_mfma_kernel<true>, dim3(nblk, (C + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
-                                   (const __bf16*)dy, lddy, part, affine, act);
-    else hipLaunchKernelGGL(head_wgrad_mfma_kernel<false>, dim3(nblk, (C + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
-                            (const __bf16*)dy, lddy, part, affine, act);
+    hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nblk, (C + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, B, H, W, C,
+                       (const __bf16*)dy, lddy, part);
     return (int)hipGetLastError();
 }
 

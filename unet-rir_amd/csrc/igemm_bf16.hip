@@ -546,7 +546,6 @@ __global__ __launch_bounds__(256) void transpose_cast_weights_batched_kernel(con
 int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s) {
     const long long M = (long long)a.g.B * a.g.PH * a.g.PW;
     if (M <= 0 || a.g.N <= 0) return 0;
-    if (igemm3_applies(a)) return launch_igemm3_fwd_bf16(&a, 1, s);                    // LDS-DMA ring: igemm3_bf16.hip
     if (igemm_bf16_tile_m(M, a.g.N, 1)) return launch_igemm2_fwd_bf16(&a, 1, s);       // small problems: igemm2_bf16.hip
     const long long mt = (M + BM - 1) / BM;
     const bool uniform = (a.g.C % BKH) == 0;
@@ -564,7 +563,6 @@ int launch_igemm_fwd_bf16(const IgemmArgsH& a, hipStream_t s) {
 int launch_igemm_fwd_bf16_x4(const IgemmArgsH* a, hipStream_t s) {
     const long long M = (long long)a[0].g.B * a[0].g.PH * a[0].g.PW;
     if (M <= 0 || a[0].g.N <= 0) return 0;
-    if (igemm3_applies(a[0]) && igemm3_applies(a[1]) && igemm3_applies(a[2]) && igemm3_applies(a[3])) return launch_igemm3_fwd_bf16(a, 4, s);
     if (igemm_bf16_tile_m(M, a[0].g.N, 4)) return launch_igemm2_fwd_bf16(a, 4, s);
     const long long mt = (M + BM - 1) / BM;
     const bool uniform = (a[0].g.C % BKH) == 0;

@@ -91,11 +91,7 @@ struct IgemmArgsH {
 // (switch off / too large): the general kernel with 128-pixel tiles.
 int igemm_bf16_tile_m(long long M, int N, int ncls);
 int launch_igemm2_fwd_bf16(const IgemmArgsH* a, int ncls, hipStream_t s);
-// The tap-table launch through an LDS-DMA ring (igemm3_bf16.hip): C % 64 == 0, N > 64.  Same pixel-tile height as the launch it
-// replaces (64 where igemm_bf16_tile_m says so, else 128): the rows of column statistics do not depend on which one runs.
 struct IgemmArgsH4 { IgemmArgsH a[4]; };
-bool igemm3_applies(const IgemmArgsH& a);
-int launch_igemm3_fwd_bf16(const IgemmArgsH* a, int ncls, hipStream_t s);
 // rows of column statistics one tap-table launch writes (= its pixel tiles)
 inline long long igemm_colstat_rows(long long M, int N, int ncls = 1) {
     const int bm = igemm_bf16_tile_m(M, N, ncls);
@@ -141,12 +137,9 @@ struct Conv3Args {
 int launch_conv3x3(const Conv3Args& a, int bf16, hipStream_t s);
 int launch_conv3x3r_bf16(const Conv3Args& a, hipStream_t s);
 bool head_mfma_applies(int W, int C);
-// affine != nullptr: x is the pre-BatchNorm tensor, act(x * scale + shift) is applied on the load path (head_mfma_bn_applies)
-bool head_mfma_bn_applies(int W, int C);
-int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s,
-                         const float* affine = nullptr, int act = 0);
+int launch_head_fwd_mfma(const void* x, int ldx, int B, int H, int W, int C, const float* w, const float* bias, float* y, int ldy, hipStream_t s);
 int launch_head_wgrad_mfma(const void* x, int ldx, int B, int H, int W, int C, const void* dy, int lddy, float* part, int max_blocks,
-                           int* nblk_out, hipStream_t s, const float* affine = nullptr, int act = 0);
+                           int* nblk_out, hipStream_t s);
 bool head_dgrad_mfma_applies(int W, int C);
 int launch_head_dgrad_mfma(const void* dy, int lddy, int B, int H, int W, const float* w, int C, void* dx, int lddx, hipStream_t s);
 bool upconv3x3g_applies(const Conv3Args& a);
@@ -166,26 +159,6 @@ int launch_conv3x3s_bf16(const Conv3Args& a, hipStream_t s);
 // One slot per stream (launches on a stream run in order; the last workgroup of a launch clears the slot); nullptr when more
 // than 128 streams are in use - the kernels then keep their fixed assignment.
 unsigned* sched_slot(hipStream_t s);
-// Arrival counters for kernels whose LAST workgroup (of the launch, or of one output tile) finishes a reduction the others fed
-// (bnfused.hip): UNETRIR_SYNC_WORDS zero-initialised words per (device, stream); words [0, UNETRIR_SYNC_TILES) count arrivals per
-// output tile, word UNETRIR_SYNC_TILES counts arrivals of a whole launch.  nullptr when no slot is available (more than 128
-// streams in use, or first use inside a stream capture): the launchers then run the separate reduction kernel.
-#define UNETRIR_SYNC_TILES 512
-#define UNETRIR_SYNC_WORDS 520
-unsigned* sync_slot(hipStream_t s);
-
-// BatchNormalization passes of small tensors in one launch per direction (bnfused.hip): words UNETRIR_SYNC_TILES .. + 3 of the sync
-// slot are the two grid-barrier counters (+ their give-up flags).  BN_FUSED_NOT_TAKEN: no slot / no occupancy answer / workspace
-// too small - the caller runs the separate launches.
-#define BN_FUSED_NOT_TAKEN (-12346)
-bool bn_fused_applies(long long P, int C, int elem_bytes);
-size_t bn_fused_ws_bytes(int C);
-int launch_bn_bwd_fused(int bf16, const void* da, int ldda, const void* x, int ldx, const void* msk, int ldm, long long P, int C,
-                        const float* affine, const float* saved, int act, void* dx, int lddx, void* g2, int ldg2, const void* g2add,
-                        int ldg2a, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t s);
-int launch_bn_fwd_fused(int bf16, const float* colstat, long long rows, const void* x, int ldx, long long P, int C, const float* gamma,
-                        const float* beta, float eps, float momentum, float* mm, float* mv, float* affine, float* saved, int act,
-                        const void* addend, int ldadd, void* y, int ldy, hipStream_t s);
 bool conv3x3p_applies(const Conv3Args& a);          // conv3x3g's layers with >= 512 tiles: persistent form, continuous K loop across tiles
 long long conv3x3p_colstat_rows(const Conv3Args& a);
 int launch_conv3x3p_bf16(const Conv3Args& a, hipStream_t s);

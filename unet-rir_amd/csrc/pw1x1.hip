@@ -263,7 +263,8 @@ bool pw1x1_applies(const PwArgs& a) {
     const long long M = (long long)a.B * a.PH * a.PW;
     if (M <= 0 || M >= (1ll << 31) || (long long)a.B * a.OH * a.OW >= (1ll << 31) || (long long)a.B * a.IH * a.IW >= (1ll << 31)) return false;
     if (a.N % 32 != 0 || a.N > 1024) return false;
-    if (!(a.C == 8 || (a.C % 16 == 0 && a.C <= 256))) return false;
+    if (!(a.C == 8 || a.C == 16 || a.C == 32 || a.C == 64 || a.C == 128 || a.C == 256)) return false;     // the KB instantiations of launch_pw1x1_bf16; other
+                                                                                                            // channel counts stay on the tap-table kernel
     if ((a.ldi & 7) || (a.ldo & 7) || (a.addend && (a.ldadd & 7))) return false;
     if ((((uintptr_t)a.in | (uintptr_t)a.out | (uintptr_t)a.w | (uintptr_t)a.addend) & 15) != 0) return false;
     if (a.SI != 1 && a.SI != 2) return false;

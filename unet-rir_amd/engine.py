@@ -14,6 +14,7 @@ Memory layout in HBM (all fp32):
     their gradient is identically zero).
 """
 import math
+import struct
 from collections import OrderedDict
 
 import torch
@@ -32,6 +33,11 @@ ALIGN = 64             # parameter offsets are multiples of 64 floats (256 B)
 
 def same_out(n, s):
     return -(-n // s)
+
+
+def _as_f32(v):
+    """v rounded to fp32, as a Python float."""
+    return struct.unpack("f", struct.pack("f", float(v)))[0]
 
 
 class ParamSpec:
@@ -221,7 +227,10 @@ class DeviceCounters:
             ms_new = self._shared.get("m_schedule", 1.0) * mu_t
             self._shared["m_schedule"] = ms_new
             return ("nadam", lr, beta1, beta2, eps, (1.0 - mu_t) / (1.0 - ms_new), mu_t1 / (1.0 - ms_new * mu_t1), 1.0 / (1.0 - beta2 ** t), grad_scale)
-        return (lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t), beta1, beta2, eps, grad_scale)
+        # the betas as the kernels see them (fp32), so that the launched step and the device-counter step (step_advance_kernel computes
+        # the same expression from its fp32 cfg in fp64) produce the same bias-corrected rate bit for bit
+        b1, b2 = _as_f32(beta1), _as_f32(beta2)
+        return (lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t), beta1, beta2, eps, grad_scale)
 
     def adam_range(self, lo, hi, *args):
         """The optimizer on the flat parameter range [lo, hi) (element offsets, multiples of the 64-float alignment)."""
@@ -246,7 +255,7 @@ class UNetEngine(DeviceCounters):
         # storage type of activations and their gradients; parameters, statistics and weight gradients are always fp32
         self.dtype = dtype
         self.fused_stats = bool(fused_stats)     # conv-epilogue BN statistics / bias gradients (bf16); False: separate reduction passes
-        self._cst_rows, self._cst_buf = {}, None
+        self._cst_rows, self._cst_buf, self._cst_gen = {}, None, ops.config_generation()
         self._cast_table = None
         self.adt = torch.float32 if dtype == "f32" else torch.bfloat16
         self.PAD = 4 if dtype == "f32" else 8          # channel granule = 16 bytes
@@ -299,13 +308,6 @@ class UNetEngine(DeviceCounters):
             self.wg_stream, self.opt_stream = self.rt.concurrent_streams(2) if overlap_wgrad else (None, None)
         self.ws_w = ops.Workspace(self.device, self.ws.nbytes) if overlap_wgrad else self.ws
         self.head_direct = ops.head6x6_supported(self.ch[0])
-        # The head kernels can take the PRE-BatchNorm tensor of dec1.cb1b and apply BatchNorm + ReLU on their load path, so that this
-        # block's activation tensor (268 MB at configs[1]) is never written or read (csrc/head_mfma.hip).  Identical results (tested),
-        # but MEASURED SLOWER: the BatchNorm-apply pass it removes takes 105 us, the two head kernels gain 53 + 58 us of vector work
-        # they cannot hide - off unless asked for (`head_bn = True` where `head_bn_supported`).
-        self.head_bn_supported = bool(self.head_direct and self.dtype == "bf16" and self.batchnorm and self.depth >= 1 and
-                                      ops.head6x6_bn_supported(self.W, self.ch[0]))
-        self.head_bn = False
         if self.head_direct:
             self.ws.reserve(512 * 2 * 36 * self.ch[0] * 4)
             self.ws_w.reserve(512 * 2 * 36 * self.ch[0] * 4)
@@ -651,6 +653,8 @@ class UNetEngine(DeviceCounters):
     def _colstat(self, name, dgrad, x: Act, n_out):
         """(rows, buffer) of fused column statistics for conv `name` (forward or data gradient), or (0, None)."""
         key = (name, dgrad)
+        if self._cst_gen != ops.config_generation():     # the switches changed: another kernel may serve the layer, with other row counts
+            self._cst_rows, self._cst_gen = {}, ops.config_generation()
         if key not in self._cst_rows:
             self._cst_rows[key] = ops.conv2d_colstat_rows(self.geo[name], dgrad, x) if self.dtype == "bf16" and self.fused_stats else 0
         rows = self._cst_rows[key]
@@ -671,34 +675,9 @@ class UNetEngine(DeviceCounters):
             self._bn_relu_fwd(name, y, out)
             return
         ops.conv2d_fwd_colstat(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y, buf)
-        # statistics rows -> affine / moving statistics -> BatchNorm + ReLU: one call (small tensors: one launch, bnfused.hip)
+        # statistics rows -> affine / moving statistics -> BatchNorm + ReLU: one call
         ops.bn_colstat_act_add(buf, rows, y, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name], out, 1, None,
                                self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
-
-    def _conv_bn_stats_fwd(self, name, x: Act, y: Act):
-        """Conv2D -> BatchNormalization statistics only (affine, saved, moving statistics): the consumer applies BatchNorm + ReLU on
-        its load path (the head: csrc/head_mfma.hip)."""
-        p = self.p
-        rows, buf = self._colstat(name, 0, x, y.C) if self.training else (0, None)
-        if rows:
-            ops.conv2d_fwd_colstat(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y, buf)
-            ops.bn_stats_colstat(buf, rows, y.P, y.C, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name],
-                                 self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
-            return
-        ops.conv2d_fwd(self.geo[name], x, self.wf(name + ".kernel"), p[name + ".bias"], y)
-        if self.training:
-            ops.bn_stats(y, p[name + ".gamma"], p[name + ".beta"], self.bn_affine[name], self.bn_saved[name], self.ws,
-                         self.moving[name + ".moving_mean"], self.moving[name + ".moving_variance"], BN_EPS, BN_MOMENTUM)
-        else:
-            ops.bn_inference_affine(p[name + ".gamma"], p[name + ".beta"], self.moving[name + ".moving_mean"],
-                                    self.moving[name + ".moving_variance"], BN_EPS, self.bn_affine[name])
-
-    def head_input(self):
-        """The activation in front of the head, relu(bn(dec1.cb1b)).  With `head_bn` it exists only inside the head kernels; it is
-        written here on request (inspection, tests) from the pre-BatchNorm tensor and the affine of the last forward pass."""
-        if self.head_bn:
-            ops.bn_apply(self.yb[1], self.bn_affine["dec1.cb1b"], self.ab[1], relu=True)
-        return self.ab[1] if self.depth >= 1 else self.a[1]
 
     def _dgrad_colsum(self, name, dy: Act, dx: Act, bias_grad, c0, c_n):
         """Data gradient of conv `name` plus the bias gradient of the layer that produced its input (channels
@@ -777,14 +756,9 @@ class UNetEngine(DeviceCounters):
             ops.conv2d_transpose_fwd(self.geo[f"dec{l}.up"], cur, self.wb(f"dec{l}.up.kernel"), p[f"dec{l}.up.bias"],
                                      self.cat[l].slice(c, c))
             self._conv_bn_relu_fwd(f"dec{l}.cb1a", self.cat[l], self.ya[l], self.aa[l])
-            if l == 1 and self.head_bn:
-                self._conv_bn_stats_fwd("dec1.cb1b", self.aa[1], self.yb[1])         # ab[1] = relu(bn(yb[1])) exists only inside the head kernels
-            else:
-                self._conv_bn_relu_fwd(f"dec{l}.cb1b", self.aa[l], self.yb[l], self.ab[l])
+            self._conv_bn_relu_fwd(f"dec{l}.cb1b", self.aa[l], self.yb[l], self.ab[l])
             cur = self.ab[l]
-        if self.head_bn:
-            ops.head6x6_fwd_bn(self.yb[1], self.bn_affine["dec1.cb1b"], 1, p["head.kernel"], p["head.bias"], self.logits)
-        elif self.head_direct:
+        if self.head_direct:
             ops.head6x6_fwd(cur, p["head.kernel"], p["head.bias"], self.logits)
         else:
             ops.conv2d_fwd(self.geo["head"], cur, p["head.kernel"], p["head.bias"], self.logits)
@@ -854,10 +828,7 @@ class UNetEngine(DeviceCounters):
                 on_ready(off)
 
         gl = self.g_logits
-        if self.head_bn:
-            with self._wg() as ws_:
-                ops.head6x6_wgrad_bn(self.yb[1], self.bn_affine["dec1.cb1b"], 1, gl, g["head.kernel"], ws_)
-        elif self.head_direct:
+        if self.head_direct:
             with self._wg() as ws_:
                 ops.head6x6_wgrad(self.ab[1] if D >= 1 else self.a[1], gl, g["head.kernel"], ws_)   # rows 2,3 of the padded kernel stay 0
         else:

@@ -191,10 +191,22 @@ class GraphEngine(DeviceCounters):
         wf = (lambda: self._ph[kname]) if h16 else (lambda: self._p[kname])       # kernel as stored ([N][T][C])
         wb = (lambda: self._pth[kname]) if h16 else (lambda: self._pt[kname])     # channel roles swapped ([C][T][N])
         # BatchNormalization statistics from the convolution's own epilogue (bf16 trunk): the tensor is not read again for them
-        rows = 0
-        if h16 and followed_by_bn and self.fused_stats and not dense and out is None:
-            rows = ops.conv2d_transpose_colstat_rows(g, x.a) if transpose else ops.conv2d_colstat_rows(g, 0, x.a)
-        cst = torch.empty((rows, co, 2), dtype=torch.float32, device=self.device) if rows else None
+        want_cst = bool(h16 and followed_by_bn and self.fused_stats and not dense and out is None)
+        cs = {"gen": None, "rows": 0, "buf": None}
+
+        def colstat():
+            """(rows, buffer) of this layer under the kernel-selection switches in effect (the row count depends on which kernel
+            serves the layer: sized again when ops.set_config has changed a switch since)."""
+            if cs["gen"] != ops.config_generation():
+                rows = 0
+                if want_cst:
+                    rows = ops.conv2d_transpose_colstat_rows(g, x.a) if transpose else ops.conv2d_colstat_rows(g, 0, x.a)
+                if rows != cs["rows"] or (rows and cs["buf"] is None):
+                    cs["buf"] = torch.empty((rows, co, 2), dtype=torch.float32, device=self.device) if rows else None
+                cs["rows"], cs["gen"] = rows, ops.config_generation()
+            return cs["rows"], cs["buf"]
+
+        colstat()
 
         def dense_dgrad(dst, add):
             if add is None:      # split-K path: the weight matrix streams from every CU
@@ -204,6 +216,7 @@ class GraphEngine(DeviceCounters):
 
         def fwd():
             y.cst = None
+            rows, cst = colstat()
             if dense:
                 ops.dense_fwd(x.a, self._p[kname], self._p[bname], y.a, self.ws)
             elif cst is not None and self.training:

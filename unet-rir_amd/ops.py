@@ -394,23 +394,6 @@ def head6x6_wgrad(x: Act, dy: Act, dw, ws: Workspace):
                                                _stream()), "head6x6_wgrad")
 
 
-def head6x6_bn_supported(W_, C_):
-    """The head kernels can take the PRE-BatchNorm tensor and apply BatchNorm + activation on their load path."""
-    return bool(_lib.lib().unetrir_head6x6_bn_supported(W_, C_))
-
-
-def head6x6_fwd_bn(x: Act, affine, act, w, bias, y: Act):
-    """head6x6_fwd(act(x * scale + shift)) without the activation tensor in between (dl_models/u_net.py:241-248); bf16 storage."""
-    check(_lib.lib().unetrir_head6x6_fwd_bn_bf16(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(affine), int(act), _p(w), _p(bias), _p(y), y.ld,
-                                                 _stream()), "head6x6_fwd_bn")
-
-
-def head6x6_wgrad_bn(x: Act, affine, act, dy: Act, dw, ws: Workspace):
-    ws.reserve(_lib.lib().unetrir_head6x6_wgrad_ws_bytes(x.C))
-    check(_lib.lib().unetrir_head6x6_wgrad_bn_bf16(_p(x), x.ld, x.B, x.H, x.W, x.C, _p(affine), int(act), _p(dy), dy.ld, _p(dw), ws.ptr,
-                                                   ws.nbytes, _stream()), "head6x6_wgrad_bn")
-
-
 def head6x6_dgrad_supported(W_, C_):
     return bool(_lib.lib().unetrir_head6x6_dgrad_supported(W_, C_))
 
@@ -573,6 +556,15 @@ def get_config():
     return {n: getattr(c, n) for n, _ in _lib.Config._fields_}
 
 
+_CONFIG_GEN = [0]
+
+
+def config_generation():
+    """Counts the set_config calls that changed a switch.  Anything derived from the dispatch (which kernel serves a layer, how many
+    rows of column statistics it writes) is cached against this number by the engines and recomputed when it moves."""
+    return _CONFIG_GEN[0]
+
+
 def set_config(**switches):
     """Replace kernel-selection switches (tests, A/B scripts), e.g. set_config(conv3x3s=0); returns the previous values."""
     old = get_config()
@@ -583,6 +575,8 @@ def set_config(**switches):
         new[k] = int(v)
     c = _lib.Config(*[new[n] for n, _ in _lib.Config._fields_])
     check(_lib.lib().unetrir_set_config(C.byref(c)), "set_config")
+    if new != old:
+        _CONFIG_GEN[0] += 1
     return old
 
 

@@ -379,7 +379,10 @@ class CheckpointManager:
         path = os.path.join(self.directory, f"ckpt-{n}.pt")
         state = {
             "format": 1, "epoch": epoch, "lr": self.trainer.lr, "adam_t": eng.adam_t,
-            "dropout_step": int(eng._shared["dropout_step"]), "dropout_seed": int(eng.dropout_seed),
+            # the BASE seed of the Dropout streams: replica r draws from stream base + r (Trainer.__init__), and every rank restores
+            # this one file (rank 0 writes it)
+            "dropout_step": int(eng._shared["dropout_step"]),
+            "dropout_seed": int((eng.dropout_seed - (self.trainer.rank if getattr(eng, "_seed_offset_by_rank", False) else 0)) & 0xFFFFFFFF),
             "optimizer": eng.optimizer, "m_schedule": float(eng._shared.get("m_schedule", 1.0)),
             "layout": [(k, tuple(s_.shape), int(s_.offset)) for k, s_ in eng.specs.items()],
             "theta": eng.theta.detach().cpu(), "adam_m": eng.adam_m.detach().cpu(), "adam_v": eng.adam_v.detach().cpu(),
@@ -408,7 +411,11 @@ class CheckpointManager:
         eng.adam_t = int(state["adam_t"])
         if "dropout_step" in state:              # the Dropout stream continues where it stopped (older checkpoints: from draw 0)
             eng._shared["dropout_step"] = int(state["dropout_step"])
-            eng.dropout_seed = int(state["dropout_seed"])
+            # base seed + this replica's rank: the replicas keep independent masks after a resume (MirroredStrategy draws per replica)
+            by_rank = self.trainer.world_size > 1
+            eng.dropout_seed = (int(state["dropout_seed"]) + (self.trainer.rank if by_rank else 0)) & 0xFFFFFFFF
+            eng._seed_offset_by_rank = by_rank
+            self.trainer._graphs = {}            # the seed is a launch argument frozen into a captured step: capture again
         if "m_schedule" in state:
             eng._shared["m_schedule"] = float(state["m_schedule"])
         eng.t_dirty = True
