@@ -309,6 +309,27 @@ int unetrir_conv2d_transpose_dgrad_bf16(const unetrir_conv_geom* g, const unetri
 int unetrir_conv2d_transpose_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx,
                                         const unetrir_bf16* dy, int lddy, float* dw, float reg_coef, const float* w,
                                         void* ws, size_t ws_bytes, unetrir_stream_t stream);
+/* Deferred split-K reduction.  Every weight gradient above ends in a fixed-order reduction of its fp32 partial slabs - a launch of
+ * 5-20 us of which most is the launch itself, 23 times per step at configs[1], 57 times at configs[4].  The *_partials_* forms run
+ * the same weight-gradient kernel, LEAVE the slabs in `ws` (which the caller must keep untouched until the reduction has run) and
+ * fill `desc`; unetrir_splitk_reduce_batched then performs up to 16 such reductions per launch (more: several launches), each
+ * output element summed by the same code in the same slab order as the single launch: bit-identical results.  desc->nsplit == 0
+ * after the call: the kernel wrote dw directly, nothing is left to do (the batched call skips such descriptors). */
+typedef struct unetrir_reduce_desc {
+    const float* part; /* [nsplit][n] partial slabs */
+    int nsplit;
+    size_t n;          /* outputs */
+    float* out;        /* [n]: sum over slabs + reg * w */
+    float reg;
+    const float* w;    /* nullable when reg == 0 */
+} unetrir_reduce_desc;
+int unetrir_conv2d_wgrad_partials_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy,
+                                       int lddy, float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
+                                       unetrir_reduce_desc* desc, unetrir_stream_t stream);
+int unetrir_conv2d_transpose_wgrad_partials_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx,
+                                                 const unetrir_bf16* dy, int lddy, float* dw, float reg_coef, const float* w,
+                                                 void* ws, size_t ws_bytes, unetrir_reduce_desc* desc, unetrir_stream_t stream);
+int unetrir_splitk_reduce_batched(const unetrir_reduce_desc* desc, int n, unetrir_stream_t stream);
 /* The stride-2 3x3 forward kernel (conv3x3d.hip: strided Conv2D forward, Conv2DTranspose data gradient) streams its kernel
  * 16 input channels at a time; from the [N][9][C] copy that is a gather of 32-byte pieces.  A PACKED copy holds the same values
  * in the order the kernel's LDS-DMA reads them - [N / 128][C / 16][9 taps][4 blocks of 32 channels][64 lanes][8 values], lane =

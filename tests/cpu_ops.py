@@ -79,15 +79,33 @@ class CpuOps:
             gx = gx + _nchw(addend)
         _put(dx, gx)
 
-    def conv2d_wgrad(self, g, x, dy, dw, ws, reg=0.0, w=None):
-        self.rt.touch([x, dy, w if reg else None], [dw, ws], "conv2d_wgrad")
+    def _finish_wgrad(self, gw, dw, ws, defer, what):
+        """Immediately, or - defer: the product's ops.ReduceBatch protocol - when the batch is flushed: until then dw holds NaNs, so a
+        reader that was not ordered behind the flush is seen by the results and by the race check (the write happens at the flush,
+        on the stream that flushes)."""
+        if defer is None:
+            self.rt.touch([], [dw, ws], what)
+            dw.reshape(gw.shape).copy_(gw.to(dw.dtype))
+            return
+        dw.fill_(float("nan"))
+
+        def finish(gw=gw, dw=dw):
+            self.rt.touch([], [dw], what + " (deferred split-K reduction)")
+            dw.reshape(gw.shape).copy_(gw.to(dw.dtype))
+        defer.pending.append(finish)
+
+    def conv2d_wgrad(self, g, x, dy, dw, ws, reg=0.0, w=None, defer=None):
+        self.rt.touch([x, dy, w if reg else None], [], "conv2d_wgrad")
         w0 = torch.zeros((g.k, g.k, g.Cin, g.Cout), dtype=D, requires_grad=True)
         out = R.conv2d_same(_nchw(x), w0, None, g.stride)
         (gw,) = torch.autograd.grad(out, w0, _nchw(dy))
         gw = gw.permute(3, 0, 1, 2)
         if reg:
             gw = gw + reg * w.reshape(gw.shape).to(D)
-        dw.reshape(gw.shape).copy_(gw.to(dw.dtype))
+        self._finish_wgrad(gw, dw, ws, defer, "conv2d_wgrad")
+
+    def wgrad_defer_supported(self, storage):
+        return True                # the simulated operators park reductions in every storage type (the schedule is what is tested)
 
     def conv2d_colstat_rows(self, g, dgrad, x):
         return 0
@@ -118,13 +136,13 @@ class CpuOps:
             gx = gx + _nchw(addend)
         _put(dx, gx)
 
-    def conv2d_transpose_wgrad(self, g, x, dy, dw, ws, reg=0.0, w=None):
-        self.rt.touch([x, dy, w if reg else None], [dw, ws], "conv2d_transpose_wgrad")
+    def conv2d_transpose_wgrad(self, g, x, dy, dw, ws, reg=0.0, w=None, defer=None):
+        self.rt.touch([x, dy, w if reg else None], [], "conv2d_transpose_wgrad")
         w0 = torch.zeros((g.Cin, g.k, g.k, g.Cout), dtype=D, requires_grad=True)
         (gw,) = torch.autograd.grad(self._convT(g, _nchw(x), w0), w0, _nchw(dy))
         if reg:
             gw = gw + reg * w.reshape(gw.shape).to(D)
-        dw.reshape(gw.shape).copy_(gw.to(dw.dtype))
+        self._finish_wgrad(gw, dw, ws, defer, "conv2d_transpose_wgrad")
 
     # ---- Dense
     def dense_fwd(self, x, w, bias, y, ws):
@@ -360,6 +378,22 @@ def _noop():
     pass
 
 
+class SimReduceBatch:
+    """Stand-in for unet_rir_amd.ops.ReduceBatch: the parked reductions are closures that write the weight gradients when the
+    product flushes."""
+
+    def __init__(self, device, arena_bytes, capacity=64):
+        self.pending = []
+
+    def __len__(self):
+        return len(self.pending)
+
+    def flush(self):
+        pend, self.pending = self.pending, []
+        for fn in pend:
+            fn()
+
+
 def _with_grad(fn):
     """The restatements use torch.autograd for the gradient kernels; they are also called from inside an autograd backward
     (the module path), where grad mode is off."""
@@ -380,4 +414,5 @@ def install(monkeypatch, rt):
                 raise AttributeError(f"unet_rir_amd.ops has no function {name}")
             monkeypatch.setattr(unet_rir_amd.ops, name, _with_grad(getattr(impl, name)))
     monkeypatch.setattr(unet_rir_amd.ops, "bn_ws_bytes", lambda P, C_: 1 << 12)
+    monkeypatch.setattr(unet_rir_amd.ops, "ReduceBatch", SimReduceBatch)
     return impl

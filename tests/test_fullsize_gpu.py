@@ -233,11 +233,17 @@ def test_train_step_invariants_at_full_size(U):
 def test_bf16_training_signal_against_the_fp32_engine_at_config_size(U):
     """How far is the benchmarked bf16-storage step from the fp32-storage step (the mode the fp32-tolerance oracle parity is
     asserted in) AT BASELINE.json configs[1] size - batch 32, 256 x 256, number_filters_0 = 64, where BatchNormalization averages
-    over 2 M elements?  Same initial variables (Keras initialisers), same batch, same dropout masks.  Observed (round 3, DESIGN.md
-    section 5): loss 1.9e-4 apart; whole gradient relative L2 0.0075, cosine 0.99997; per tensor median relative L2 0.02, the
-    deep encoder levels 0.10-0.14, the information-vector branch 0.29 (cosine 0.958: its gradient is 300x smaller than the trunk's
-    and is a sum with heavy cancellation over the bf16-stored dL/dz of the 16 x 16 bottleneck); 50 Adam steps: losses within 7e-4.
-    The bounds below are those observations with margin."""
+    over 2 M elements?  Same initial variables (Keras initialisers), same batch, same dropout masks.  Observed (rounds 3 and 4,
+    DESIGN.md section 5, profiles/r04_bf16_noise_trace.json): loss 1.9e-4 apart; whole gradient relative L2 0.0075, cosine 0.99997;
+    per tensor median relative L2 0.02, the deep encoder levels 0.10-0.14, the information-vector branch 0.29 (cosine 0.958).
+    Where it comes from (scripts/bf16_noise_trace.py): the stored FORWARD tensors of the two engines are 1.1-1.9 % apart, so at every
+    BatchNormalization -> ReLU a per-cent fraction of the ReLU inputs has the other sign, and the ELEMENTWISE gradient tensors move
+    apart by 3-10 % per block (dL/dlogits 1.5 %, behind the first BatchNorm backward 9.9 %, dL/dz of the bottleneck 29 %).  Weight
+    gradients sum that over ~10^5..10^6 pixels and stay at 1-14 %; the information-vector branch sums dL/dz itself through a 16-channel
+    bottleneck and keeps all of it.  Handing that branch dL/dz BEFORE its rounding to bf16 (an fp32 side output of the data-gradient
+    kernel: round 4, built and measured) changes nothing: 0.2865 / 0.2906 / 0.2899 either way - the stored rounding of dL/dz is not
+    the cause.  50 Adam steps: losses within 7e-4.  The bounds below are those observations x 1.15 (the kernels are deterministic and
+    the inputs seeded: a regression of 15 % trips them)."""
     import bench
     H = 256
     spec_in, emb, spec_out = bench.synthetic_batch(B, H, H, torch.device(DEV), 1234)
@@ -273,14 +279,14 @@ def test_bf16_training_signal_against_the_fp32_engine_at_config_size(U):
         cos = float((g16 * g32).sum()) / (n32 * float(g16.norm()))
         rels.append(rel)
         if n.startswith("vec."):
-            assert rel <= 0.5 and cos >= 0.90, (n, rel, cos)
+            assert rel <= 0.335 and cos >= 0.950, (n, rel, cos)       # observed worst: vec.dense.kernel 0.2906 / 0.9578
         else:
-            assert rel <= 0.25 and cos >= 0.97, (n, rel, cos)
-    assert len(rels) == 77 - 13 and sorted(rels)[len(rels) // 2] <= 0.05
+            assert rel <= 0.16 and cos >= 0.988, (n, rel, cos)        # observed worst: enc5.cb1.kernel 0.1376 / 0.9905
+    assert len(rels) == 77 - 13 and sorted(rels)[len(rels) // 2] <= 0.025         # observed 0.0198
     w32 = torch.cat([g.flatten() for g in grads["f32"].values()])
     w16 = torch.cat([g.flatten() for g in grads["bf16"].values()])
-    assert float((w16 - w32).norm() / w32.norm()) <= 0.02
-    assert float((w16 * w32).sum() / (w16.norm() * w32.norm())) >= 0.9995
+    assert float((w16 - w32).norm() / w32.norm()) <= 0.009                        # observed 0.0075
+    assert float((w16 * w32).sum() / (w16.norm() * w32.norm())) >= 0.99995       # observed 0.999972
     # 50 Adam steps from the same variables with the same dropout stream: the two loss trajectories stay together
     traj = {}
     for dt, eng in engs.items():
@@ -292,4 +298,4 @@ def test_bf16_training_signal_against_the_fp32_engine_at_config_size(U):
         torch.cuda.synchronize()
         traj[dt] = [float(v) for v in ls]
     assert traj["f32"][-1] < 0.8 * traj["f32"][0] and traj["bf16"][-1] < 0.8 * traj["bf16"][0]
-    assert max(abs(a - b) / a for a, b in zip(traj["f32"], traj["bf16"])) <= 3e-3
+    assert max(abs(a - b) / a for a, b in zip(traj["f32"], traj["bf16"])) <= 1e-3         # observed 6.1e-4 ... 6.7e-4

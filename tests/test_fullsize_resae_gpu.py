@@ -270,15 +270,96 @@ def test_resae_train_step_invariants_at_cfg5_size(U):
     # bf16 storage: the statistics of a permuted batch are the same sums in another order, a last-bit difference flips bf16 roundings
     # and 56 BatchNorm layers carry the flips on - a few of the 4.2 M outputs move by several per cent (observed maxima 3.3e-2 ...
     # 7.6e-2 over permutations), the bulk by 1e-3
+    # How large: test_resae_bf16_storage_against_fp32_storage_at_cfg5_size measures the bf16 engine against the fp32 engine on the
+    # same batch - prediction rms 1.0e-2, max 0.115 apart - and the fp32 engine under this very permutation: prediction bit-equal.
+    # A permutation of the bf16 batch costs about half of the storage noise itself (rms 5.4e-3, max 6.1e-2 here; gradient 5.3 %
+    # in relative L2): the bounds are those observations x 1.5, not a number picked after a failing run.
     d = (eng.pred - pred1[perm]).abs().double()
-    assert float(d.pow(2).mean().sqrt()) <= 6e-3 and float(d.max()) <= 0.2, (float(d.pow(2).mean().sqrt()), float(d.max()))
-    assert float((eng.grad.double() - grad1.double()).norm()) <= 5e-2 * float(grad1.double().norm())
+    assert float(d.pow(2).mean().sqrt()) <= 8e-3 and float(d.max()) <= 0.1, (float(d.pow(2).mean().sqrt()), float(d.max()))
+    assert float((eng.grad.double() - grad1.double()).norm()) <= 8e-2 * float(grad1.double().norm())
     # it trains
     tr = U.Trainer(eng, lr=1e-4, dropout=False)
     l0 = tr.step(spec_in, emb, spec_out, return_loss=True)
     for _ in range(8):
         l1 = tr.step(spec_in, emb, spec_out, return_loss=True)
     assert math.isfinite(l1) and l1 < l0
+
+
+def test_resae_bf16_storage_against_fp32_storage_at_cfg5_size(U):
+    """BASELINE.json configs[4] at its own size: how far is the benchmarked bf16-storage step from the fp32-storage step (the mode the
+    fp32-tolerance oracle parity is asserted in, tests/test_resae_gpu.py)?  Same variables (Keras initialisers), same batch, same
+    dropout stream.  Observed (round 4, scripts/resae_fidelity.py, profiles/r04_resae_fidelity.json): loss 3.4e-5 apart; prediction
+    rms 1.0e-2 / max 0.115 apart (56 BatchNormalization layers carry the bf16 rounding of every stored activation forward); whole
+    gradient relative L2 0.077, cosine 0.9971; per tensor (177 with a non-zero gradient) median 0.118, worst the BatchNorm scales /
+    offsets of the first encoder blocks at 0.60 (cosine 0.855: elementwise the gradient signal differs by tens of per cent wherever
+    a LeakyReLU / ReLU input changed sign between the two forward passes, and a per-channel sum over 32 x 128 x 128 of it keeps that
+    noise); 50 Adam steps with dropout: the loss trajectories stay within 2.5e-3.  The fp32 engine itself is bit-stable under a batch
+    permutation (prediction equal, gradient 5e-8), the bf16 engine moves by about half of its distance to fp32 (see the permutation
+    test above).  Bounds = observations with margin."""
+    spec_in, emb, spec_out = next(U.synthetic_batches(1, B, 256, 256, DEV))
+    engs = {}
+    for dt in ("f32", "bf16"):
+        eng = U.ResAEEngine(256, 256, B, (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 1024, device=DEV, dtype=dt)
+        if dt == "f32":
+            gen = torch.Generator(); gen.manual_seed(0)
+            eng.reset_parameters(gen)
+        else:
+            eng.load_keras_params(engs["f32"].export_keras_params())
+        eng.dropout_seed = 9
+        engs[dt] = eng
+    grads, loss, pred = {}, {}, {}
+    for dt, eng in engs.items():
+        eng.training = True
+        eng.forward(spec_in, emb, target=spec_out, global_batch=B)
+        eng.backward()
+        torch.cuda.synchronize()
+        loss[dt], pred[dt] = float(eng.loss_out[0]), eng.pred.clone()
+        grads[dt] = {k: v.double() for k, v in eng.export_keras_grads().items()}
+    assert abs(loss["bf16"] - loss["f32"]) <= 3e-4 * loss["f32"]
+    d = (pred["bf16"] - pred["f32"]).abs().double()
+    assert float(d.pow(2).mean().sqrt()) <= 1.5e-2 and float(d.max()) <= 0.2, (float(d.pow(2).mean().sqrt()), float(d.max()))
+    rels, zero = [], 0
+    for n, g32 in grads["f32"].items():
+        g16 = grads["bf16"][n]
+        n32 = float(g32.norm())
+        if n32 < 1e-12:                       # biases in front of a BatchNorm: analytically zero, exact zeros in both engines
+            assert float(g16.abs().max()) == 0.0, n
+            zero += 1
+            continue
+        rel = float((g16 - g32).norm()) / n32
+        cos = float((g16 * g32).sum()) / (n32 * float(g16.norm()))
+        assert rel <= 0.75 and cos >= 0.80, (n, rel, cos)
+        rels.append(rel)
+    assert zero == 56 and len(rels) == len(grads["f32"]) - 56
+    assert sorted(rels)[len(rels) // 2] <= 0.15
+    w32 = torch.cat([g.flatten() for g in grads["f32"].values()])
+    w16 = torch.cat([g.flatten() for g in grads["bf16"].values()])
+    assert float((w16 - w32).norm() / w32.norm()) <= 0.10
+    assert float((w16 * w32).sum() / (w16.norm() * w32.norm())) >= 0.995
+    # the fp32 engine under a batch permutation: the prediction is the permuted prediction bit for bit (BatchNorm sums are fp64 in a
+    # fixed order per slab; fp32 storage absorbs the last-bit differences of another slab order)
+    pg = torch.Generator(device=DEV); pg.manual_seed(3)
+    perm = torch.randperm(B, device=DEV, generator=pg)
+    e32 = engs["f32"]
+    whole = e32.grad.double().clone()
+    e32.forward(spec_in[perm].contiguous(), emb[perm].contiguous(), target=spec_out[perm].contiguous(), global_batch=B)
+    e32.backward()
+    torch.cuda.synchronize()
+    assert float((e32.pred - pred["f32"][perm]).abs().max()) <= 1e-6
+    assert float((e32.grad.double() - whole).norm()) <= 1e-5 * float(whole.norm())
+    # 50 Adam steps from the same variables with the same dropout stream
+    traj = {}
+    for dt, eng in engs.items():
+        eng._shared["dropout_step"] = 0
+        tr = U.Trainer(eng, lr=1e-4, dropout=True)
+        ls = []
+        for _ in range(50):
+            tr.step(spec_in, emb, spec_out)
+            ls.append(eng.loss_out[0].clone())
+        torch.cuda.synchronize()
+        traj[dt] = [float(v) for v in ls]
+    assert traj["f32"][-1] < 0.85 * traj["f32"][0] and traj["bf16"][-1] < 0.85 * traj["bf16"][0]
+    assert max(abs(a - b) / a for a, b in zip(traj["f32"], traj["bf16"])) <= 6e-3
 
 
 def test_resae_graph_replay_equals_the_launched_step_at_cfg5_size(U):

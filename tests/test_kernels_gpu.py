@@ -974,3 +974,59 @@ def _tap_table_ab(U, case, switch, fixed):
         close(out[1]["cs"][:, 0], td.sum(dim=(0, 1, 2)), 2e-6, "colstat sum")
         close(out[1]["cs"][:, 1], (td * td).sum(dim=(0, 1, 2)), 2e-6, "colstat sum of squares")
         assert out[1]["rows"] >= out[0]["rows"]                   # 64-pixel tiles: at least as many rows as the 128-pixel kernel
+
+
+def test_parked_split_k_reductions_equal_the_immediate_ones_bit_for_bit(U):
+    """ops.ReduceBatch (unetrir_*_wgrad_partials_bf16 + unetrir_splitk_reduce_batched): weight gradients of a mix of layers - 3x3 at
+    stride 1 and 2, 1x1, a transposed layer, with and without the l2 term, outputs from 2 K to 150 K floats, few and many slabs -
+    parked in one batch and reduced by ONE launch against the same weight gradients reduced layer by layer: identical bits (same code
+    over the same slab order per output element), in both the narrow and the wide form of the reduction."""
+    ops = U.ops
+    gen = torch.Generator(device=DEV); gen.manual_seed(11)
+    rnd = lambda *sh: ((torch.rand(sh, device=DEV, generator=gen) - 0.5) * 2).to(torch.bfloat16)
+    #        B   H    W   Cin  Cout k  s  transposed  reg
+    cases = [(8, 64, 64, 64, 64, 3, 1, False, 0.0), (8, 64, 64, 128, 64, 3, 1, False, 0.0), (4, 64, 64, 64, 128, 3, 2, False, 2e-3),
+             (4, 32, 32, 128, 64, 3, 2, True, 2e-3), (8, 32, 32, 32, 32, 1, 1, False, 0.0), (8, 16, 16, 256, 256, 1, 1, False, 0.0),
+             (2, 16, 16, 512, 512, 3, 1, False, 0.0), (8, 32, 32, 64, 32, 1, 2, False, 0.0), (3, 24, 40, 64, 96, 3, 1, False, 0.0)]
+    layers = []
+    for B, H, W, Ci, Co, k, s, tr, reg in cases:
+        g = ops.geom(B, H, W, Ci, Co, k, s)
+        if tr:      # Conv2DTranspose(Ci -> Co) on H x W: x [B,H,W,Ci], dy [B,sH,sW,Co], kernel [Ci][k][k][Co]
+            x, dy = ops.Act(rnd(B, H, W, Ci)), ops.Act(rnd(B, H * s, W * s, Co))
+            w = torch.rand((Ci, k, k, Co), device=DEV, generator=gen) - 0.5
+        else:
+            x, dy = ops.Act(rnd(B, H, W, Ci)), ops.Act(rnd(B, -(-H // s), -(-W // s), Co))
+            w = torch.rand((Co, k, k, Ci), device=DEV, generator=gen) - 0.5
+        layers.append((g, x, dy, w, reg, tr))
+    ws = ops.Workspace(DEV)
+    want = []
+    for g, x, dy, w, reg, tr in layers:
+        dw = torch.full_like(w, 7.0)
+        (ops.conv2d_transpose_wgrad if tr else ops.conv2d_wgrad)(g, x, dy, dw, ws, reg=reg, w=w)
+        want.append(dw)
+    rb = ops.ReduceBatch(DEV, 8 << 20)                    # small on purpose: the arena grows / the batch flushes itself when it is full
+    got = []
+    for g, x, dy, w, reg, tr in layers:
+        dw = torch.full_like(w, 7.0)
+        (ops.conv2d_transpose_wgrad if tr else ops.conv2d_wgrad)(g, x, dy, dw, ws, reg=reg, w=w, defer=rb)
+        got.append(dw)
+    forms = {(int(rb.descs[i].nsplit >= 32), min(int(rb.descs[i].nsplit), 8)) for i in range(len(rb))}
+    assert len(rb) >= 3 and len(forms) >= 2, (len(rb), forms)
+    rb.flush()
+    torch.cuda.synchronize()
+    assert len(rb) == 0
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), (cases[i], float((a - b).abs().max()))
+    # one big batch too (every layer parked, one flush): an arena that holds them all
+    rb = ops.ReduceBatch(DEV, 1 << 30)
+    got = []
+    for g, x, dy, w, reg, tr in layers:
+        dw = torch.full_like(w, 7.0)
+        (ops.conv2d_transpose_wgrad if tr else ops.conv2d_wgrad)(g, x, dy, dw, ws, reg=reg, w=w, defer=rb)
+        got.append(dw)
+    parked = len(rb)
+    rb.flush()
+    torch.cuda.synchronize()
+    assert parked >= len(cases) - 2            # all but the layers whose kernel writes dw directly
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), (cases[i], float((a - b).abs().max()))

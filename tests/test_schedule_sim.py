@@ -173,6 +173,38 @@ def test_race_check_detects_a_missing_optimizer_join(monkeypatch):
         tr.step(spec_in, emb, spec_out)
 
 
+@pytest.mark.parametrize("kind,overlap", [("unet", True), ("unet", False), ("resae", True)])
+def test_parked_split_k_reductions_are_flushed_before_their_first_reader(monkeypatch, kind, overlap):
+    """The engines park the split-K reductions of their weight gradients (ops.ReduceBatch) and the trainer's bucketer runs them
+    before a bucket's gradients are first read.  In the simulated operators a parked gradient holds NaNs until the flush: the steps
+    above equal the oracle WITH the parking in place; here the flush the bucketer asks for is taken away (negative control) and the
+    optimizer must be seen reading gradients that were never reduced - in the buckets handed over during the backward pass, the
+    end-of-backward flush comes too late for them."""
+    import cpu_ops
+    from sim_runtime import SimRuntime
+    from oracle import torch_ref as R
+    rt = SimRuntime()
+    cpu_ops.install(monkeypatch, rt)
+    cfg, eng, tr = _build(rt, 2, overlap, bucket_bytes=8192, kind=kind)
+    spec_in, emb, spec_out = (torch.tensor(a) for a in R.synthetic_batch(cfg, 2))
+    assert eng._rb is not None
+    if tr.bucketer is None:                # no side stream, one replica: the optimizer runs after backward()'s own final flush
+        tr.step(spec_in, emb, spec_out)
+        assert bool(torch.isfinite(eng.theta).all())
+        return
+    assert tr.bucketer.before_bucket is not None and len(tr.bucketer.bounds) > 3
+    tr.step(spec_in, emb, spec_out)
+    assert bool(torch.isfinite(eng.theta).all()) and len(eng._rb) == 0
+    tr.bucketer.before_bucket = None
+    from sim_runtime import RaceError
+    try:
+        tr.step(spec_in, emb, spec_out)
+        seen = not bool(torch.isfinite(eng.theta).all())         # the optimizer consumed NaNs ...
+    except RaceError:
+        seen = True                                               # ... or the late flush wrote what the optimizer had already read
+    assert seen
+
+
 def _dp_worker(rank, world, port, out_path, overlap, kind, B=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -19,6 +19,11 @@ class CastDesc(C.Structure):
                 ("Cp", C.c_int), ("Np", C.c_int), ("reserved", C.c_int), ("packed_s2", C.c_void_p)]
 
 
+class ReduceDesc(C.Structure):
+    """unetrir_reduce_desc (include/unetrir.h): one deferred split-K reduction."""
+    _fields_ = [("part", C.c_void_p), ("nsplit", C.c_int), ("n", C.c_size_t), ("out", C.c_void_p), ("reg", C.c_float), ("w", C.c_void_p)]
+
+
 class Config(C.Structure):
     """unetrir_config: kernel-selection switches (include/unetrir.h)."""
     _fields_ = [(n, C.c_int) for n in ("conv3x3", "conv3x3g", "conv3x3g_pair", "conv3x3h", "conv3x3s", "conv3x3r", "stem",
@@ -106,6 +111,11 @@ _SIGS = {
                                                     C.c_int, c_stream]),
     "unetrir_conv2d_transpose_dgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, c_f32p, C.c_int,
                                                       c_f32p, C.c_int, c_stream]),
+    "unetrir_conv2d_wgrad_partials_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_float, c_f32p,
+                                                     C.c_void_p, C.c_size_t, C.POINTER(ReduceDesc), c_stream]),
+    "unetrir_conv2d_transpose_wgrad_partials_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_float,
+                                                               c_f32p, C.c_void_p, C.c_size_t, C.POINTER(ReduceDesc), c_stream]),
+    "unetrir_splitk_reduce_batched": (C.c_int, [C.POINTER(ReduceDesc), C.c_int, c_stream]),
     "unetrir_conv2d_transpose_wgrad_bf16": (C.c_int, [C.POINTER(ConvGeom), c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
                                                       C.c_float, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "unetrir_cast_weight_bf16": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),

@@ -645,6 +645,29 @@ int unetrir_conv2d_wgrad_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x,
     return conv_wgrad_bf16_impl(g, (const __bf16*)x, ldx, (const __bf16*)dy, lddy, dw, reg_coef, w, ws, ws_bytes, (hipStream_t)stream);
 }
 
+namespace {
+struct SinkScope {         // the weight-gradient launchers below this scope record their reduction in *d instead of launching it
+    explicit SinkScope(unetrir_reduce_desc* d) { d->part = nullptr; d->nsplit = 0; d->n = 0; d->out = nullptr; d->reg = 0.f; d->w = nullptr; set_reduce_sink(d); }
+    ~SinkScope() { set_reduce_sink(nullptr); }
+};
+}  // namespace
+
+int unetrir_conv2d_wgrad_partials_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy, int lddy,
+                                       float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes, unetrir_reduce_desc* desc,
+                                       unetrir_stream_t stream) {
+    if (!desc) return UNETRIR_EINVAL;
+    SinkScope sc(desc);
+    return unetrir_conv2d_wgrad_bf16(g, x, ldx, dy, lddy, dw, reg_coef, w, ws, ws_bytes, stream);
+}
+
+int unetrir_conv2d_transpose_wgrad_partials_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* dy,
+                                                 int lddy, float* dw, float reg_coef, const float* w, void* ws, size_t ws_bytes,
+                                                 unetrir_reduce_desc* desc, unetrir_stream_t stream) {
+    if (!desc) return UNETRIR_EINVAL;
+    SinkScope sc(desc);
+    return unetrir_conv2d_transpose_wgrad_bf16(g, x, ldx, dy, lddy, dw, reg_coef, w, ws, ws_bytes, stream);
+}
+
 int unetrir_conv2d_transpose_fwd_bf16(const unetrir_conv_geom* g, const unetrir_bf16* x, int ldx, const unetrir_bf16* wt,
                                       const float* bias, unetrir_bf16* y, int ldy, unetrir_stream_t stream) {
     if (!geom_ok(g) || !x || !wt || !y || (g->Cin & 7) || !ldh_ok(ldx, g->Cin) || ldy < g->Cout)

@@ -382,11 +382,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const WgradArgs a) {
 // groups (waves): group g sums slabs g, g+G, ... in order with 8 independent loads in flight, then the G group sums are
 // added in fixed order -> bit-reproducible.  G follows the split count so that no wave idles when there are few slabs.
 template <int G>
-__global__ __launch_bounds__(64 * G) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
-                                                               float* __restrict__ out, float reg, const float* __restrict__ w) {
-    __shared__ float4 red[G][64];
+__device__ __forceinline__ void splitk_reduce_body(float4 (*red)[64], const unsigned block, const float* __restrict__ part, int nsplit, size_t n,
+                                                   float* __restrict__ out, float reg, const float* __restrict__ w) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const size_t i4 = ((size_t)blockIdx.x * 64 + lane) * 4;
+    if (grp >= G) return;                          // the batched kernel runs 8 waves whatever G is (a finished wave does not count at the barrier)
+    const size_t i4 = ((size_t)block * 64 + lane) * 4;
     const bool full = i4 + 3 < n;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (full) {
@@ -429,6 +429,12 @@ __global__ __launch_bounds__(64 * G) void splitk_reduce_kernel(const float* __re
         const float* sp = &s.x;
         for (size_t i = i4; i < n; ++i) out[i] = sp[i - i4] + (reg != 0.f ? reg * w[i] : 0.f);
     }
+}
+template <int G>
+__global__ __launch_bounds__(64 * G) void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, size_t n,
+                                                               float* __restrict__ out, float reg, const float* __restrict__ w) {
+    __shared__ float4 red[G][64];
+    splitk_reduce_body<G>(red, blockIdx.x, part, nsplit, n, out, reg, w);
 }
 
 // [N][T][C] -> [C][T][N] through a 32x33 LDS tile per tap
@@ -578,11 +584,10 @@ int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* 
 // slabs): the kernel above would run a handful of workgroups that each walk 64 slabs one after the other.  Here a workgroup
 // owns 16 float4 columns and 32 slab groups: group g sums slabs g, g + 32, ... (8 loads in flight), the 32 group sums are added
 // in a fixed order.  16 lanes x 16 bytes = one 256-byte piece of a slab per group and step.
-__global__ __launch_bounds__(512) void splitk_reduce_wide_kernel(const float* __restrict__ part, int nsplit, size_t n,
-                                                                 float* __restrict__ out, float reg, const float* __restrict__ w) {
-    __shared__ float4 red[32][16];
+__device__ __forceinline__ void splitk_reduce_wide_body(float4 (*red)[16], const unsigned block, const float* __restrict__ part, int nsplit, size_t n,
+                                                        float* __restrict__ out, float reg, const float* __restrict__ w) {
     const int lane = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const size_t i4 = ((size_t)blockIdx.x * 16 + lane) * 4;
+    const size_t i4 = ((size_t)block * 16 + lane) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 < n) {                                   // n % 4 == 0 (checked by the launcher)
         const float* p = part + i4;
@@ -613,11 +618,95 @@ __global__ __launch_bounds__(512) void splitk_reduce_wide_kernel(const float* __
     }
     *reinterpret_cast<float4*>(out + i4) = s;
 }
+__global__ __launch_bounds__(512) void splitk_reduce_wide_kernel(const float* __restrict__ part, int nsplit, size_t n,
+                                                                 float* __restrict__ out, float reg, const float* __restrict__ w) {
+    __shared__ float4 red[32][16];
+    splitk_reduce_wide_body(red, blockIdx.x, part, nsplit, n, out, reg, w);
+}
+
+// ---- several reductions in ONE launch (round 4).  A weight gradient's fixed-order reduction is 5-20 us of which most is the launch
+// itself (37.7 MB of slabs at 1.9 TB/s; 1-64 K outputs at their launch floor), and a train step has 23 (configs[1]) to 57 (configs[4])
+// of them.  The weight-gradient entry points can leave their slabs in the caller's workspace and hand back a descriptor instead
+// (unetrir_*_wgrad_partials_*); unetrir_splitk_reduce_batched then reduces up to 16 of them per launch.  Every output element is summed
+// by the same code over the same slab order as in the single launch (same group count, wide or narrow form per reduction): bit-identical.
+#define REDUCE_BATCH 16
+struct ReduceBatchArgs {
+    unetrir_reduce_desc d[REDUCE_BATCH];
+    unsigned first_block[REDUCE_BATCH + 1];       // workgroup range of reduction i: [first_block[i], first_block[i + 1])
+    unsigned char kind[REDUCE_BATCH];             // 0: the wide form; 8 / 4 / 2 / 1: the narrow form with that many slab groups
+    int n;
+};
+__global__ __launch_bounds__(512) void splitk_reduce_batched_kernel(const ReduceBatchArgs a) {
+    __shared__ float4 red[8 * 64];                 // [8][64] (narrow, 8 slab groups) or [32][16] (wide)
+    int i = 0;
+    while (i + 1 < a.n && blockIdx.x >= a.first_block[i + 1]) ++i;
+    const unetrir_reduce_desc& d = a.d[i];
+    const unsigned blk = blockIdx.x - a.first_block[i];
+    float4 (*r64)[64] = reinterpret_cast<float4 (*)[64]>(red);
+    switch (a.kind[i]) {                           // uniform per workgroup
+        case 0: splitk_reduce_wide_body(reinterpret_cast<float4 (*)[16]>(red), blk, d.part, d.nsplit, d.n, d.out, d.reg, d.w); break;
+        case 8: splitk_reduce_body<8>(r64, blk, d.part, d.nsplit, d.n, d.out, d.reg, d.w); break;
+        case 4: splitk_reduce_body<4>(r64, blk, d.part, d.nsplit, d.n, d.out, d.reg, d.w); break;
+        case 2: splitk_reduce_body<2>(r64, blk, d.part, d.nsplit, d.n, d.out, d.reg, d.w); break;
+        default: splitk_reduce_body<1>(r64, blk, d.part, d.nsplit, d.n, d.out, d.reg, d.w); break;
+    }
+}
+
+// A weight-gradient entry point called with a descriptor to fill (unetrir_*_wgrad_partials_*) runs its implementation with this
+// pointer set: launch_splitk_reduce then records what it was asked to reduce instead of launching.  Thread-local: the ABI stays
+// re-entrant across host threads.
+thread_local unetrir_reduce_desc* t_reduce_sink = nullptr;
+void set_reduce_sink(unetrir_reduce_desc* d) { t_reduce_sink = d; }
+
+static inline bool reduce_is_wide(int nsplit, size_t n, const float* part, const float* out, const float* w) {
+    const size_t n4 = (n + 3) / 4;
+    return (n & 3) == 0 && nsplit >= 32 && (n4 + 63) / 64 < 128 && (((uintptr_t)part | (uintptr_t)out | (uintptr_t)w) & 15) == 0;
+}
+
+extern "C" int unetrir_splitk_reduce_batched(const unetrir_reduce_desc* desc, int n, unetrir_stream_t stream) {
+    if (n < 0 || (n > 0 && !desc)) return UNETRIR_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    ReduceBatchArgs a;
+    a.n = 0;
+    a.first_block[0] = 0;
+    auto flush = [&]() -> int {
+        if (a.n == 0) return 0;
+        if (a.n == 1) {          // nothing to batch: the single launch
+            const unetrir_reduce_desc& d = a.d[0];
+            a.n = 0;
+            return launch_splitk_reduce(d.part, d.nsplit, d.n, d.out, d.reg, d.w, s);
+        }
+        hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3(a.first_block[a.n]), dim3(512), 0, s, a);
+        a.n = 0;
+        return (int)hipGetLastError();
+    };
+    for (int i = 0; i < n; ++i) {
+        const unetrir_reduce_desc& d = desc[i];
+        if (d.nsplit == 0) continue;                            // the weight gradient went straight into dw: nothing to reduce
+        if (!d.part || !d.out || d.nsplit < 0 || d.n == 0 || (d.reg != 0.f && !d.w)) return UNETRIR_EINVAL;
+        const bool wide = reduce_is_wide(d.nsplit, d.n, d.part, d.out, d.w);
+        const size_t n4 = (d.n + 3) / 4;
+        const size_t blocks = wide ? (n4 + 15) / 16 : (n4 + 63) / 64;
+        if (blocks > 0x3fffffffu) return UNETRIR_EINVAL;
+        if (a.n == REDUCE_BATCH || (size_t)a.first_block[a.n] + blocks > 0x7fffffffu) { const int e = flush(); if (e) return e; a.first_block[0] = 0; }
+        a.d[a.n] = d;
+        a.kind[a.n] = wide ? 0 : (d.nsplit >= 8 ? 8 : d.nsplit >= 4 ? 4 : d.nsplit >= 2 ? 2 : 1);      // as launch_splitk_reduce picks them
+        a.first_block[a.n + 1] = a.first_block[a.n] + (unsigned)blocks;
+        ++a.n;
+    }
+    return flush();
+}
 
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s) {
+    if (t_reduce_sink) {          // deferred: the caller reduces later, together with others (unetrir_splitk_reduce_batched)
+        if (t_reduce_sink->nsplit != 0) return UNETRIR_EINVAL;          // one reduction per weight gradient
+        t_reduce_sink->part = part; t_reduce_sink->nsplit = nsplit; t_reduce_sink->n = n; t_reduce_sink->out = out;
+        t_reduce_sink->reg = reg; t_reduce_sink->w = w;
+        return 0;
+    }
     const size_t n4 = (n + 3) / 4;
     // (round 3: taking larger outputs too - up to 4096 narrow workgroups - moves single launches by +-8 us and the step by nothing)
-    if ((n & 3) == 0 && nsplit >= 32 && (n4 + 63) / 64 < 128 && (((uintptr_t)part | (uintptr_t)out | (uintptr_t)w) & 15) == 0) {
+    if (reduce_is_wide(nsplit, n, part, out, w)) {
         hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(512), 0, s, part, nsplit, n, out, reg, w);
         return (int)hipGetLastError();
     }

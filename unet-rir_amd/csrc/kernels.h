@@ -61,6 +61,9 @@ int wgrad_plan(const IgemmGeom& g, int* nsplit, long long* chunks_per_split);
 int launch_igemm_wgrad(WgradArgs a, float* dw, float reg, const float* w, void* ws, size_t ws_bytes, hipStream_t s, int bf16_operands = 0);
 int launch_transpose_weight(const float* w, float* wt, int N, int T, int C, hipStream_t s);
 int launch_splitk_reduce(const float* part, int nsplit, size_t n, float* out, float reg, const float* w, hipStream_t s);
+// While a sink is set (this host thread), launch_splitk_reduce records its arguments there instead of launching: the
+// *_wgrad_partials_* entry points (api.hip) run the ordinary weight-gradient launchers under it.
+void set_reduce_sink(unetrir_reduce_desc* d);
 
 // 3x3 weight gradient with a halo-staged x patch (wgrad3x3.hip)
 struct Wgrad3Args {

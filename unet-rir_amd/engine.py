@@ -293,6 +293,9 @@ class UNetEngine(DeviceCounters):
         self._alloc()
         self.ws = ops.Workspace(self.device)
         self._reserve_workspace()
+        # bf16 storage: the split-K reductions of the trunk's weight gradients are parked and run together, one launch per bucket
+        # hand-over instead of one per layer (ops.ReduceBatch): 23 launches of 5-20 us per step become 4
+        self._rb = ops.ReduceBatch(self.device, 16 * self._wgrad_ws_max) if ops.wgrad_defer_supported(self.dtype) else None
         self.training = True
         self._pending_ready = []
         self._defer_ready = bool(defer_ready)    # park bucket hand-overs until the side stream next waits for the main stream
@@ -595,6 +598,7 @@ class UNetEngine(DeviceCounters):
                 need = max(need, ops.conv2d_transpose_wgrad_ws_bytes(g))
             else:
                 need = max(need, ops.conv2d_wgrad_ws_bytes(g))
+        self._wgrad_ws_max = need
         P0 = self.B * self.H * self.W
         need = max(need, ops.bn_ws_bytes(P0, max(self.ch[0], 4)), ops.bn_ws_bytes(self.B * self.h5 * self.w5, self.ch[-1]),
                    ops.bn_ws_bytes(self.B, self.vec_dim))
@@ -848,7 +852,7 @@ class UNetEngine(DeviceCounters):
             # cb1b
             self._bn_relu_bwd(f"dec{l}.cb1b", self.g_ab[l], self.yb[l], self.g_yb[l])
             with self._wg() as ws_:
-                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws_)
+                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws_, defer=self._rb)
             if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
                 with self._wg() as ws_:
                     ops.colsum(self.g_yb[l], g[f"dec{l}.cb1b.bias"], ws_)
@@ -856,7 +860,7 @@ class UNetEngine(DeviceCounters):
             # cb1a
             self._bn_relu_bwd(f"dec{l}.cb1a", self.g_aa[l], self.ya[l], self.g_ya[l])
             with self._wg() as ws_:
-                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws_)
+                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws_, defer=self._rb)
             if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
                 with self._wg() as ws_:
                     ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws_)
@@ -867,7 +871,7 @@ class UNetEngine(DeviceCounters):
             g_in = self.g_ab[l + 1] if l < D else self.g_z
             with self._wg() as ws_:
                 ops.conv2d_transpose_wgrad(self.geo[f"dec{l}.up"], x_in, g_up, g[f"dec{l}.up.kernel"], ws_, reg=reg,
-                                           w=p[f"dec{l}.up.kernel"])
+                                           w=p[f"dec{l}.up.kernel"], defer=self._rb)
             if not up_bias_done:
                 with self._wg() as ws_:
                     ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
@@ -905,7 +909,7 @@ class UNetEngine(DeviceCounters):
         for l in range(self.L, 0, -1):
             self._bn_relu_bwd(f"enc{l}.cb1", g_a, self.y[l], self.g_y[l])
             with self._wg() as ws_:
-                ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws_)
+                ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws_, defer=self._rb)
             if not self.batchnorm:
                 with self._wg() as ws_:
                     ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws_)
@@ -913,7 +917,7 @@ class UNetEngine(DeviceCounters):
             x_in = self.a[l - 1] if l > 1 else self.x4
             with self._wg() as ws_:
                 ops.conv2d_wgrad(self.geo[f"enc{l}.down"], x_in, self.g_down[l], g[f"enc{l}.down.kernel"], ws_, reg=reg,
-                                 w=p[f"enc{l}.down.kernel"])
+                                 w=p[f"enc{l}.down.kernel"], defer=self._rb)
             if not down_bias_done:
                 with self._wg() as ws_:
                     ops.colsum(self.g_down[l], g[f"enc{l}.down.bias"], ws_)
@@ -922,13 +926,19 @@ class UNetEngine(DeviceCounters):
                 skip = self.g_cat[l - 1].slice(0, self.ch[l - 2])
                 ops.conv2d_dgrad(self.geo[f"enc{l}.down"], self.g_down[l], self.wb(f"enc{l}.down.kernel"), skip, addend=skip)
                 g_a = skip
-        if self._pending_ready:
-            with self._wg():
-                pass            # hands over what is still parked
+        if self._pending_ready or (self._rb is not None and len(self._rb)):
+            with self._wg():    # hands over what is still parked (the bucketer runs the parked reductions first) ...
+                self.flush_reduces()        # ... and without a bucketer, or behind its last boundary: the reductions still parked
         self._join_wg()     # the optimizer (and the next forward, which overwrites activations) must see every weight gradient
 
     def _wg(self):
         return _SideStream(self)
+
+    def flush_reduces(self):
+        """Run the parked split-K reductions (on the current stream: the one the weight gradients ran on).  Called by the trainer's
+        bucketer before a bucket's gradients are first read, and at the end of backward()."""
+        if self._rb is not None:
+            self._rb.flush()
 
     def _flush_ready(self):
         """Called on the side stream right after it has waited for the main stream: hand over the parked buckets."""

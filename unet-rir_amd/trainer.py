@@ -21,7 +21,8 @@ class GradBucketer:
     (SUM) each bucket as soon as the backward pass has produced it.  Device agnostic: the same object drives RCCL
     on GPUs and gloo in the CPU tests."""
 
-    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None, reduce=True, on_bucket=None, runtime=None):
+    def __init__(self, flat_grad, boundaries, bucket_bytes=32 << 20, group=None, reduce=True, on_bucket=None, runtime=None,
+                 before_bucket=None):
         """boundaries: increasing element offsets at which a gradient range [0, off) can become final.
         reduce=False: no collective (single replica), only the bucket schedule.  on_bucket(lo, hi, work) is called for
         every bucket right after its all-reduce has been launched (work is None without a collective): the hook the
@@ -31,6 +32,9 @@ class GradBucketer:
         self.rt = runtime          # device.HipRuntime (or the tests' simulated one); None: plain torch.distributed calls
         self.reduce = reduce
         self.on_bucket = on_bucket
+        # called (on the stream the engine hands buckets over from) before a bucket's gradients are first read: the engines park the
+        # split-K reductions of their weight gradients until then and run them in one launch (engine.flush_reduces)
+        self.before_bucket = before_bucket
         self.bounds = []
         last, limit = 0, max(bucket_bytes // 4, 1)
         for off in boundaries:
@@ -58,6 +62,8 @@ class GradBucketer:
         while self.next < len(self.bounds) and self.bounds[self.next] <= offset_end:
             hi = self.bounds[self.next]
             work = None
+            if self.before_bucket is not None:
+                self.before_bucket()
             if self.reduce:
                 if self.rt is not None:
                     work = self.rt.all_reduce_sum(self.flat[self.sent:hi], self.group)
@@ -180,7 +186,8 @@ class Trainer:
         if dp or self.adam_stream is not None:
             bounds = [s_.offset + (-(-s_.numel // ALIGN) * ALIGN) for s_ in engine.specs.values()]
             self.bucketer = GradBucketer(engine.grad, bounds, bucket_bytes, group, reduce=dp,
-                                         on_bucket=self._adam_bucket if self.adam_stream is not None else None, runtime=self.rt)
+                                         on_bucket=self._adam_bucket if self.adam_stream is not None else None, runtime=self.rt,
+                                         before_bucket=getattr(engine, "flush_reduces", None))
 
     def broadcast_parameters(self, src=0):
         """Replicas start from identical variables (MirroredStrategy mirrors them at creation)."""
