@@ -96,9 +96,19 @@ def cpu_baseline(F0, H, W):
 
 
 def traffic(dtype):
-    """HBM bytes per launch of the dominant conv kernel from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction); None if the file is absent.  It is a
-    recorded profile of this same command, not a live measurement (counters cannot be read from inside the process)."""
+    """HBM bytes per launch of the dominant conv kernel from the committed PMC passes: profiles/r04_roofline_table.json (made by
+    scripts/roofline_table.py from the kernel-trace statistics and the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_round.sh,
+    gfx950 FETCH_SIZE x2 correction), else the older profiles/pmc_traffic.json; None if neither is there.  It is a recorded profile
+    of this same command, not a live measurement (counters cannot be read from inside the process)."""
+    if dtype == "bf16":
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_roofline_table.json")) as f:
+                t = json.load(f)
+            k = t["kernels"][t["dominant_kernel"]]
+            if k.get("traffic_bytes_per_launch"):
+                return k["traffic_bytes_per_launch"], f'{t["dominant_kernel"]}: bytes per launch, profiles/r04_roofline_table.json'
+        except Exception:
+            pass
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)[dtype]
@@ -129,6 +139,75 @@ def _dominant(fam, steps, dtype, where):
     ach = ffl[6] / (fms[6] * 1e-3) / 1e12
     return {"kernel": "conv3x3p_bf16_kernel", "calls_per_step": counts[6] / steps, "avg_call_ms": fms[6] / counts[6],
             "algorithmic_gflop_per_step": ffl[6] / steps / 1e9, "achieved": ach, "frac": ach / MFMA_PEAK_TFLOPS[dtype], "measured_on": where}
+
+
+class DpProbe:
+    """What the data-parallel schedule does with its gradient buckets, measured on INSTRUMENTED steps outside the timed region
+    (every bracket is an event record in a stream; the timed steps carry none).  Per bucket: bytes, the time from the start of the
+    step to the point where the bucket was handed to the collective (its gradients final, on the stream that hands it over), the time
+    from there until the stream that waits for the all-reduce saw it complete, and the effective rate; per step: the length of the
+    backward pass and the EXPOSED TAIL - what is left of the step after the last backward kernel (all-reduce of the last buckets +
+    their optimizer launches), which is what bounds weak-scaling efficiency from above.  Works on any runtime object of
+    unet_rir_amd/device.py's interface (tests/test_bench_launch.py drives it on two gloo ranks over the simulated runtime)."""
+
+    def __init__(self, trainer):
+        self.tr, self.rt = trainer, trainer.rt
+        self.steps = []
+
+    def __enter__(self):
+        rt, tr = self.rt, self.tr
+        self._saved = (rt.all_reduce_sum, rt.wait_work, tr.apply_gradients)
+        probe = self
+
+        def all_reduce_sum(tensor, group=None):
+            ev = rt.record(timing=True)
+            work = probe._saved[0](tensor, group)
+            probe._cur["buckets"].append({"bytes": tensor.numel() * tensor.element_size(), "issue": ev, "done": None, "work": work})
+            return work
+
+        def wait_work(work):
+            probe._saved[1](work)
+            for b in probe._cur["buckets"]:
+                if b["work"] is work and b["done"] is None:
+                    b["done"] = rt.record(timing=True)
+
+        def apply_gradients():
+            probe._cur["bwd_end"] = rt.record(timing=True)       # every backward launch (and the join with the side stream) is queued
+            probe._saved[2]()
+            probe._cur["end"] = rt.record(timing=True)
+
+        rt.all_reduce_sum, rt.wait_work, tr.apply_gradients = all_reduce_sum, wait_work, apply_gradients
+        return self
+
+    def __exit__(self, *exc):
+        self.rt.all_reduce_sum, self.rt.wait_work, self.tr.apply_gradients = self._saved
+        return False
+
+    def step(self, fn):
+        self._cur = {"buckets": []}
+        self._cur["start"] = self.rt.record(timing=True)
+        fn()
+        self.steps.append(self._cur)
+
+    def summary(self):
+        """Means over the probed steps."""
+        rt, n = self.rt, len(self.steps)
+        if n == 0:
+            return None
+        nb = len(self.steps[0]["buckets"])
+        out = {"probed_steps": n, "buckets": [], "note": "instrumented steps outside the timed region"}
+        for i in range(nb):
+            issue = sum(rt.elapsed_ms(st["start"], st["buckets"][i]["issue"]) for st in self.steps) / n
+            have = [st for st in self.steps if st["buckets"][i]["done"] is not None]
+            dur = sum(rt.elapsed_ms(st["buckets"][i]["issue"], st["buckets"][i]["done"]) for st in have) / len(have) if have else None
+            by = self.steps[0]["buckets"][i]["bytes"]
+            out["buckets"].append({"bytes": by, "issued_at_ms": issue, "issue_to_complete_ms": dur,
+                                   "effective_GBps": (by / (dur * 1e-3) / 1e9) if dur else None})
+        out["backward_end_at_ms"] = sum(rt.elapsed_ms(st["start"], st["bwd_end"]) for st in self.steps) / n
+        out["step_ms"] = sum(rt.elapsed_ms(st["start"], st["end"]) for st in self.steps) / n
+        out["exposed_tail_ms"] = out["step_ms"] - out["backward_end_at_ms"]
+        out["allreduce_bytes_per_step"] = sum(b["bytes"] for b in self.steps[0]["buckets"])
+        return out
 
 
 class Runner:
@@ -197,6 +276,12 @@ class Runner:
         dt, fam = self.timed(lambda: tr.step(spec_in, emb, spec_out), steps, warmup, level)
         res = {"value": batch * self.world * steps / dt, "ms_per_step": dt * 1e3 / steps, "steps": steps, "warmup": warmup,
                "dtype": dtype, "loss": tr.last_loss(), "params": eng.n_params(), "fam": fam, "overlap": overlap}
+        if (self.world > 1 or a.force_dp) and prof:
+            with DpProbe(tr) as probe:           # after the timed region
+                for _ in range(5):
+                    probe.step(lambda: tr.step(spec_in, emb, spec_out))
+                self.sync()
+                res["dp_probe"] = probe.summary()
         if self.world > 1:
             res["replicas_in_sync"] = self.replicas_in_sync(eng.theta)
         del tr, eng
@@ -256,9 +341,9 @@ class Runner:
             del tr, model
             torch.cuda.empty_cache()
         # The launched form keeps the host busy for 4.7-5.4 ms of a 6.3 ms step (~590 launches): on a box with a slow host it becomes
-        # host-bound (9.3 ms seen once), the graph replay does not.  The line's value is the faster of the two forms a user can pick
-        # (`Trainer(graph=...)`), named in `schedule`; both are reported.
-        best = "launched" if out["launched"]["value"] >= out["graph"]["value"] else "graph"
+        # host-bound (9.3 ms seen once), the graph replay does not.  `value` is ALWAYS the default form (launched, side-stream
+        # schedule: what `ResAE(...)` + `Trainer(model)` give); the graph replay (`Trainer(graph=True)`) stands beside it.
+        best = "launched"
         res = {"workload": "BASELINE.json configs[4]: ResAE filters (32,64,128,256), k 3, s 2, latent 32, n_neurons 1024, batch 32 of "
                            "[2,256,256], full train step, " + ("bf16 storage of the convolutional trunk" if dtype == "bf16" else "fp32 storage"),
                "schedule": "launches, side-stream weight gradients" if best == "launched" else "HIP-graph replay, single stream (Trainer(graph=True))",
@@ -396,6 +481,14 @@ def main():
     full = world == 1 and not args.lean              # side figures are single-GPU material
 
     eng_res = run.engine_run(head_dtype, args.steps, args.warmup, overlap)
+    single_ref = None
+    if world > 1 and not args.lean and not args.rehearse_shared_gpu:
+        # thr(N) / (N thr(1)) against a 1-GPU figure of the SAME invocation: rank 0 runs the same per-GPU workload alone (no
+        # collective, the other GPUs idle at the barrier behind it) - same box, same process, same kernels
+        if rank == 0:
+            one = Runner(U, args, 1, 0, device).engine_run(head_dtype, args.steps, args.warmup, overlap, prof=False)
+            single_ref = {"value": one["value"], "ms_per_step": one["ms_per_step"], "steps": one["steps"], "warmup": one["warmup"]}
+        run.sync()
     mod_res = None
     if args.through_module or full:
         mod_res = run.module_run(head_dtype, args.steps if args.through_module else min(args.steps, 10), min(args.warmup, 3), overlap)
@@ -408,7 +501,7 @@ def main():
             f32_res = run.engine_run("f32", max(args.steps, 20), max(min(args.warmup, 3), 2), overlap)
             f32_sub = run.engine_run("f32", 5, 2, False) if overlap and not args.no_prof else None
         if (args.f0, args.size, args.depth, args.batch) == (64, 256, 4, 32):
-            c4 = run.engine_run("bf16", 3, 2, overlap, prof=False, f0=128, size=512, depth=5, batch=16)
+            c4 = run.engine_run("bf16", 10, 2, overlap, prof=False, f0=128, size=512, depth=5, batch=16)
             configs["cfg4_model_1gpu"] = {
                 "workload": "BASELINE.json configs[3]'s model on ONE GPU: UNet 5 down/5 up, number_filters_0=128, kernels=3, batch 16 of "
                             "[2,512,512], full train step, bf16 storage", "value": c4["value"], "unit": "spectrograms/s",
@@ -456,6 +549,14 @@ def main():
                    "schedule": "side-stream weight gradients + bucket-wise Adam" if overlap else "single stream"},
         "loss": head["loss"],
     }
+    if eng_res.get("dp_probe") is not None or single_ref is not None:
+        out["data_parallel"] = {"world_size": world, "bucket_mb": args.bucket_mb}
+        if eng_res.get("dp_probe") is not None:
+            out["data_parallel"].update(eng_res["dp_probe"])
+        if single_ref is not None:
+            out["data_parallel"]["single_gpu_same_invocation"] = single_ref
+            out["data_parallel"]["scaling_efficiency"] = head["value"] / (world * single_ref["value"])
+            out["data_parallel"]["scaling_efficiency_note"] = "thr(N) / (N thr(1)), thr(1) = rank 0 alone in this same process; the driver computes its own from the per-N lines"
     if eng_res.get("fam") is not None:
         out["roofline"] = roofline_block(eng_res, sub, head_dtype)
     if mod_res is not None:

@@ -1,5 +1,6 @@
 """A/B of one kernel-selection switch on the full train step, alternating two engines in ONE process (cfg 2, bf16):
-python scripts/ab_switch.py conv3x3s [--no-overlap] [rounds]        (attr:head_bn flips an ENGINE attribute instead of a library switch)"""
+python scripts/ab_switch.py conv3x3s [--no-overlap] [--resae] [rounds]        (attr:park_reduces flips an ENGINE attribute instead of a
+library switch; --resae: BASELINE.json configs[4] instead of configs[1])"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +10,7 @@ import bench
 name = sys.argv[1]
 attr = name[5:] if name.startswith("attr:") else None
 overlap = "--no-overlap" not in sys.argv
+resae = "--resae" in sys.argv
 rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 6
 dev = torch.device("cuda:0")
 trainers = {}
@@ -22,7 +24,10 @@ def flip(val, eng=None):
 
 for val in (1, 0):
     flip(val)
-    eng = U.UNetEngine(256, 256, 32, F0=64, k=3, device=dev, dtype="bf16", overlap_wgrad=overlap)
+    if resae:
+        eng = U.ResAEEngine(256, 256, 32, (32, 64, 128, 256), (3, 3, 3, 3), (2, 2, 2, 2), 32, 1024, device=dev, dtype="bf16", overlap_wgrad=overlap)
+    else:
+        eng = U.UNetEngine(256, 256, 32, F0=64, k=3, device=dev, dtype="bf16", overlap_wgrad=overlap)
     flip(val, eng)
     g = torch.Generator(); g.manual_seed(0)
     eng.reset_parameters(g)

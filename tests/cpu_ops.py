@@ -382,8 +382,9 @@ class SimReduceBatch:
     """Stand-in for unet_rir_amd.ops.ReduceBatch: the parked reductions are closures that write the weight gradients when the
     product flushes."""
 
-    def __init__(self, device, arena_bytes, capacity=64):
+    def __init__(self, device, arena_bytes, capacity=64, park_max_bytes=None):
         self.pending = []
+        self.park_max_bytes = park_max_bytes
 
     def __len__(self):
         return len(self.pending)

@@ -10,6 +10,7 @@ them is a data race on the real device, and raises ``RaceError`` here.  So the t
 hand-over to the collective and the bucket-wise optimizer on its own stream.
 """
 import contextlib
+import time
 
 import torch
 import torch.distributed as dist
@@ -40,6 +41,7 @@ class SimStream:
 class SimEvent:
     def __init__(self, clock):
         self.clock = dict(clock)
+        self.t = time.perf_counter()       # launches execute eagerly: host time of the record stands in for the device time stamp
 
 
 class SimWork:
@@ -103,9 +105,12 @@ class SimRuntime:
     def current_stream(self):
         return self._stack[-1]
 
-    def record(self, stream=None):
+    def record(self, stream=None, timing=False):
         s = stream if stream is not None else self.current_stream()
         return SimEvent(s.clock)
+
+    def elapsed_ms(self, a, b):
+        return (b.t - a.t) * 1e3
 
     def wait(self, stream, ev):
         stream.merge(ev.clock)

@@ -45,3 +45,66 @@ def test_shared_gpu_rehearsal_also_refuses_to_run_without_a_gpu():
     assert r.returncode != 0
     assert "visible GPUs" in r.stderr or "MI355X" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def _probe_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, ROOT)
+        from _pytest.monkeypatch import MonkeyPatch
+        import bench
+        import cpu_ops
+        import unet_rir_amd as U
+        from oracle import torch_ref as R
+        from sim_runtime import SimRuntime
+        mpatch = MonkeyPatch()
+        rt = SimRuntime()
+        cpu_ops.install(mpatch, rt)
+        H, W, F0, B = 32, 32, 4, 2
+        eng = U.UNetEngine(H, W, B, F0=F0, k=3, device="cpu", runtime=rt, overlap_wgrad=True, n_replicas=world)
+        g = torch.Generator(); g.manual_seed(0)
+        eng.reset_parameters(g)
+        tr = U.Trainer(eng, lr=1e-3, dropout=False, world_size=world, bucket_bytes=8192)
+        tr.broadcast_parameters(0)
+        cfg = R.Config(H, W, F0, 3)
+        spec_in, emb, spec_out = (torch.tensor(a) for a in R.synthetic_batch(cfg, B, seed_name=f"r{rank}"))
+        with bench.DpProbe(tr) as probe:
+            for _ in range(3):
+                probe.step(lambda: tr.step(spec_in, emb, spec_out))
+        # the probe has put the runtime and the trainer back as they were
+        assert rt.all_reduce_sum.__func__ is SimRuntime.all_reduce_sum and tr.apply_gradients.__func__ is U.Trainer.apply_gradients
+        torch.save({"summary": probe.summary(), "n_buckets": len(tr.bucketer.bounds), "grad_bytes": eng.grad.numel() * 4,
+                    "theta": eng.theta.clone()}, f"{out_path}.{rank}")
+        mpatch.undo()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_probe_of_the_bench_line_on_two_gloo_ranks(tmp_path):
+    """What `bench.py --gpus N` adds to its line for N > 1 (`data_parallel`: per-bucket hand-over time and issue -> completion of the
+    all-reduce, end of the backward pass, exposed tail) comes from bench.DpProbe around the product Trainer.step.  No 8-GPU node is
+    available to the build, so the probe is exercised here: two gloo ranks, the product schedule (side-stream weight gradients,
+    bucket-wise Adam) on the simulated runtime - one row per gradient bucket, bytes adding up to the gradient buffer, hand-over times
+    in bucket order inside the step, a tail that is the step minus the backward pass; replicas stay in sync with the probe in place."""
+    import torch
+    import torch.multiprocessing as mp
+    world = 2
+    out = str(tmp_path / "probe")
+    mp.spawn(_probe_worker, args=(world, 32700 + (os.getpid() % 1500), out), nprocs=world, join=True)
+    res = [torch.load(f"{out}.{r}", weights_only=False) for r in range(world)]
+    assert torch.equal(res[0]["theta"], res[1]["theta"])
+    for r in res:
+        s = r["summary"]
+        assert s["probed_steps"] == 3 and len(s["buckets"]) == r["n_buckets"] > 3
+        assert sum(b["bytes"] for b in s["buckets"]) == r["grad_bytes"] == s["allreduce_bytes_per_step"]
+        at = [b["issued_at_ms"] for b in s["buckets"]]
+        assert all(a2 >= a1 for a1, a2 in zip(at, at[1:])) and at[0] > 0.0
+        assert all(b["issue_to_complete_ms"] is not None and b["issue_to_complete_ms"] >= 0.0 for b in s["buckets"])
+        assert 0.0 < s["backward_end_at_ms"] <= s["step_ms"] and abs(s["exposed_tail_ms"] - (s["step_ms"] - s["backward_end_at_ms"])) < 1e-9
+        assert at[-1] <= s["step_ms"]

@@ -22,11 +22,16 @@ class HipRuntime:
     def current_stream(self):
         return torch.cuda.current_stream(self.device)
 
-    def record(self, stream=None):
-        """A new event recorded on `stream` (default: the current stream)."""
-        ev = torch.cuda.Event()
+    def record(self, stream=None, timing=False):
+        """A new event recorded on `stream` (default: the current stream).  timing: the event keeps a time stamp (elapsed_ms)."""
+        ev = torch.cuda.Event(enable_timing=bool(timing))
         ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
         return ev
+
+    def elapsed_ms(self, a, b):
+        """Milliseconds between two timing events (waits for the later one)."""
+        b.synchronize()
+        return a.elapsed_time(b)
 
     def wait(self, stream, ev):
         """Work queued on `stream` after this call runs after `ev`."""

@@ -293,9 +293,11 @@ class UNetEngine(DeviceCounters):
         self._alloc()
         self.ws = ops.Workspace(self.device)
         self._reserve_workspace()
-        # bf16 storage: the split-K reductions of the trunk's weight gradients are parked and run together, one launch per bucket
-        # hand-over instead of one per layer (ops.ReduceBatch): 23 launches of 5-20 us per step become 4
-        self._rb = ops.ReduceBatch(self.device, 16 * self._wgrad_ws_max) if ops.wgrad_defer_supported(self.dtype) else None
+        # bf16 storage: the split-K reductions of weight gradients with SMALL slab sets (<= 16 MB: small images, narrow layers) are parked
+        # and run together (ops.ReduceBatch); the 37.7 MB slab sets of configs[1] reduce at once, while they are still in the
+        # Infinity Cache (parking them measured 0.06-0.09 ms per step slower)
+        self._rb = ops.ReduceBatch(self.device, 96 << 20, park_max_bytes=16 << 20) if ops.wgrad_defer_supported(self.dtype) else None
+        self.park_reduces = self._rb is not None          # False: every weight gradient reduces its slabs at once (A/B, scripts/ab_switch.py)
         self.training = True
         self._pending_ready = []
         self._defer_ready = bool(defer_ready)    # park bucket hand-overs until the side stream next waits for the main stream
@@ -852,7 +854,7 @@ class UNetEngine(DeviceCounters):
             # cb1b
             self._bn_relu_bwd(f"dec{l}.cb1b", self.g_ab[l], self.yb[l], self.g_yb[l])
             with self._wg() as ws_:
-                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws_, defer=self._rb)
+                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1b"], self.aa[l], self.g_yb[l], g[f"dec{l}.cb1b.kernel"], ws_, defer=self._rb if self.park_reduces else None)
             if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
                 with self._wg() as ws_:
                     ops.colsum(self.g_yb[l], g[f"dec{l}.cb1b.bias"], ws_)
@@ -860,7 +862,7 @@ class UNetEngine(DeviceCounters):
             # cb1a
             self._bn_relu_bwd(f"dec{l}.cb1a", self.g_aa[l], self.ya[l], self.g_ya[l])
             with self._wg() as ws_:
-                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws_, defer=self._rb)
+                ops.conv2d_wgrad(self.geo[f"dec{l}.cb1a"], self.cat[l], self.g_ya[l], g[f"dec{l}.cb1a.kernel"], ws_, defer=self._rb if self.park_reduces else None)
             if not self.batchnorm:      # a bias in front of BatchNorm has an identically zero gradient (dy sums to 0 per channel)
                 with self._wg() as ws_:
                     ops.colsum(self.g_ya[l], g[f"dec{l}.cb1a.bias"], ws_)
@@ -871,7 +873,7 @@ class UNetEngine(DeviceCounters):
             g_in = self.g_ab[l + 1] if l < D else self.g_z
             with self._wg() as ws_:
                 ops.conv2d_transpose_wgrad(self.geo[f"dec{l}.up"], x_in, g_up, g[f"dec{l}.up.kernel"], ws_, reg=reg,
-                                           w=p[f"dec{l}.up.kernel"], defer=self._rb)
+                                           w=p[f"dec{l}.up.kernel"], defer=self._rb if self.park_reduces else None)
             if not up_bias_done:
                 with self._wg() as ws_:
                     ops.colsum(g_up, g[f"dec{l}.up.bias"], ws_)
@@ -909,7 +911,7 @@ class UNetEngine(DeviceCounters):
         for l in range(self.L, 0, -1):
             self._bn_relu_bwd(f"enc{l}.cb1", g_a, self.y[l], self.g_y[l])
             with self._wg() as ws_:
-                ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws_, defer=self._rb)
+                ops.conv2d_wgrad(self.geo[f"enc{l}.cb1"], self.down[l], self.g_y[l], g[f"enc{l}.cb1.kernel"], ws_, defer=self._rb if self.park_reduces else None)
             if not self.batchnorm:
                 with self._wg() as ws_:
                     ops.colsum(self.g_y[l], g[f"enc{l}.cb1.bias"], ws_)
@@ -917,7 +919,7 @@ class UNetEngine(DeviceCounters):
             x_in = self.a[l - 1] if l > 1 else self.x4
             with self._wg() as ws_:
                 ops.conv2d_wgrad(self.geo[f"enc{l}.down"], x_in, self.g_down[l], g[f"enc{l}.down.kernel"], ws_, reg=reg,
-                                 w=p[f"enc{l}.down.kernel"], defer=self._rb)
+                                 w=p[f"enc{l}.down.kernel"], defer=self._rb if self.park_reduces else None)
             if not down_bias_done:
                 with self._wg() as ws_:
                     ops.colsum(self.g_down[l], g[f"enc{l}.down.bias"], ws_)

@@ -80,7 +80,8 @@ class GraphEngine(DeviceCounters):
         self._pending_ready = []
         # the split-K reductions of the weight gradients are parked and run together (ops.ReduceBatch; engine.UNetEngine): one launch
         # per bucket hand-over / full arena instead of one per convolution (configs[4]: 57 per step)
-        self._rb = ops.ReduceBatch(self.device, 256 << 20) if ops.wgrad_defer_supported(dtype) else None
+        self._rb = ops.ReduceBatch(self.device, 96 << 20, park_max_bytes=16 << 20) if ops.wgrad_defer_supported(dtype) else None
+        self.park_reduces = self._rb is not None
         self._p, self._g, self._pt = {}, {}, {}
 
     @property
@@ -242,9 +243,9 @@ class GraphEngine(DeviceCounters):
         def bwd():
             with self._wg() as ws_:       # leaves of the backward pass: side stream when there is one
                 if transpose:
-                    ops.conv2d_transpose_wgrad(g, x.a, y.g, self._g[kname], ws_, reg=reg(), w=self._p[kname], defer=self._rb)
+                    ops.conv2d_transpose_wgrad(g, x.a, y.g, self._g[kname], ws_, reg=reg(), w=self._p[kname], defer=self._rb if self.park_reduces else None)
                 else:
-                    ops.conv2d_wgrad(g, x.a, y.g, self._g[kname], ws_, reg=reg(), w=self._p[kname], defer=self._rb)
+                    ops.conv2d_wgrad(g, x.a, y.g, self._g[kname], ws_, reg=reg(), w=self._p[kname], defer=self._rb if self.park_reduces else None)
                 if not followed_by_bn:        # a bias in front of BatchNorm has an identically zero gradient
                     ops.colsum(y.g, self._g[bname], ws_)
             if dense:

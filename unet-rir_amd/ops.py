@@ -189,10 +189,15 @@ class ReduceBatch:
     (configs[1]) to 57 (configs[4]) such reductions of 5-20 us, most of it launch latency.  The owner flushes before anything reads
     the gradients (bucket hand-over, optimizer) and on the stream the weight gradients ran on."""
 
-    def __init__(self, device, arena_bytes, capacity=64):
+    def __init__(self, device, arena_bytes, capacity=64, park_max_bytes=None):
+        """park_max_bytes: weight gradients whose slabs are larger reduce at once instead (None: park everything).  Measured on
+        MI355X (scripts/ab_switch.py attr:park_reduces): the 37.7 MB slab sets of configs[1] are read back from the Infinity Cache when
+        reduced at once and from HBM when parked - parking them costs 0.06-0.09 ms per step; the few-MB slab sets of configs[4] gain
+        0.1 (side-stream schedule) to 0.57 ms (single stream) from sharing a launch."""
         self.arena = Workspace(device, int(arena_bytes))
         self.descs = (_lib.ReduceDesc * capacity)()
         self.n, self.used, self.capacity = 0, 0, capacity
+        self.park_max_bytes = park_max_bytes
 
     def __len__(self):
         return self.n
@@ -216,7 +221,7 @@ class ReduceBatch:
 
 
 def _wgrad(name, g, x: Act, dy: Act, dw, ws: Workspace, reg, w, defer, need):
-    if defer is not None and x.sfx == "bf16":
+    if defer is not None and x.sfx == "bf16" and (defer.park_max_bytes is None or need <= defer.park_max_bytes):
         got = defer.take(need)
         if got is None and len(defer):
             defer.flush()                  # arena or table full: reduce what is there (same stream), then defer this one
