@@ -26,6 +26,9 @@ constexpr int DD_ROWS = 128;         // rows of w (n) per slice
 constexpr int DD_COLS = 1024;        // output columns per workgroup (4 waves x 64 lanes x float4)
 constexpr int DD_PF = 16;            // rows requested ahead
 
+}  // namespace
+
+// (outside the anonymous namespace: rocprofv3 lists kernels with internal linkage under an empty name)
 __global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ w,
                                                           int B, int K, int N, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) float dyT[DD_ROWS][DD_BT];
@@ -68,8 +71,6 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(const float* __restric
     for (int b = 0; b < DD_BT; ++b)
         if (b < B) *reinterpret_cast<float4*>(po + (size_t)b * K) = acc[b];
 }
-
-}  // namespace
 
 bool dense_dgrad_applies(int B, int K, int N) { return B >= 1 && B <= DD_BT && K > 0 && (K & 3) == 0 && N > 0; }
 

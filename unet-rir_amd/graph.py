@@ -78,9 +78,11 @@ class GraphEngine(DeviceCounters):
             self.wg_stream, self.opt_stream = self.rt.concurrent_streams(2) if overlap_wgrad else (None, None)
         self.ws_w = ops.Workspace(self.device, 1 << 20) if self.wg_stream is not None else self.ws     # the side stream's own
         self._pending_ready = []
-        # the split-K reductions of the weight gradients are parked and run together (ops.ReduceBatch; engine.UNetEngine): one launch
-        # per bucket hand-over / full arena instead of one per convolution (configs[4]: 57 per step)
-        self._rb = ops.ReduceBatch(self.device, 96 << 20, park_max_bytes=16 << 20) if ops.wgrad_defer_supported(dtype) else None
+        # the split-K reductions of the weight gradients are parked and run together (ops.ReduceBatch): one launch per bucket
+        # hand-over / full arena instead of one per convolution (configs[4]: 57 per step).  Every slab set is parked here: measured on
+        # configs[4] (scripts/sweep_park.py, engines alternating in one process) 6.78 ms per step with none parked, 6.69-6.79 with only
+        # the sets <= 4 / 16 / 64 MB parked, 6.47 with all of them (single stream: 6.82 / 6.61-6.76 / 6.49)
+        self._rb = ops.ReduceBatch(self.device, 512 << 20) if ops.wgrad_defer_supported(dtype) else None
         self.park_reduces = self._rb is not None
         self._p, self._g, self._pt = {}, {}, {}
 
