@@ -819,7 +819,7 @@ class UNetEngine(DeviceCounters):
             s_ = self.specs[name]
             off = s_.offset + (-(-s_.numel // ALIGN) * ALIGN)
             if self.wg_stream is None:
-                on_ready(off)
+                self._hand_over(on_ready, off)
                 return
             # A bucket's gradients come from both streams (weight gradients: side stream; BatchNorm / fused bias
             # gradients: main stream).  The SIDE stream hands the bucket over once it has waited for the main stream's
@@ -831,7 +831,7 @@ class UNetEngine(DeviceCounters):
                 return
             self.rt.wait(self.wg_stream, self.rt.record())
             with self.rt.on(self.wg_stream):
-                on_ready(off)
+                self._hand_over(on_ready, off)
 
         gl = self.g_logits
         if self.head_direct:
@@ -936,6 +936,13 @@ class UNetEngine(DeviceCounters):
     def _wg(self):
         return _SideStream(self)
 
+    def _hand_over(self, fn, off):
+        """on_ready(off): the gradient range [0, off) is final.  A consumer that does not run the parked split-K reductions itself
+        (the trainer's bucketer does, lazily, at its bucket boundaries: GradBucketer.before_bucket) gets them run first."""
+        if getattr(getattr(fn, "__self__", None), "before_bucket", None) is None:
+            self.flush_reduces()
+        fn(off)
+
     def flush_reduces(self):
         """Run the parked split-K reductions (on the current stream: the one the weight gradients ran on).  Called by the trainer's
         bucketer before a bucket's gradients are first read, and at the end of backward()."""
@@ -946,7 +953,7 @@ class UNetEngine(DeviceCounters):
         """Called on the side stream right after it has waited for the main stream: hand over the parked buckets."""
         pend, self._pending_ready = self._pending_ready, []
         for fn, off in pend:
-            fn(off)
+            self._hand_over(fn, off)
 
     def _join_wg(self):
         if self.wg_stream is not None:

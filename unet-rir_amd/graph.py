@@ -126,7 +126,13 @@ class GraphEngine(DeviceCounters):
     def _flush_ready(self):
         pend, self._pending_ready = self._pending_ready, []
         for fn, off in pend:
-            fn(off)
+            self._hand_over(fn, off)
+
+    def _hand_over(self, fn, off):
+        """on_ready(off) for a consumer that may not run the parked reductions itself (engine.UNetEngine._hand_over)."""
+        if getattr(getattr(fn, "__self__", None), "before_bucket", None) is None:
+            self.flush_reduces()
+        fn(off)
 
     def flush_reduces(self):
         """Run the parked split-K reductions on the current stream (the one the weight gradients ran on): the trainer's bucketer calls
@@ -603,7 +609,7 @@ class GraphEngine(DeviceCounters):
             if on_ready is not None and names:
                 off = max(self.specs[n].offset + (-(-self.specs[n].numel // ALIGN) * ALIGN) for n in names)
                 if self.wg_stream is None:
-                    on_ready(off)
+                    self._hand_over(on_ready, off)
                 else:
                     # side-stream schedule: the prefix is final once the side stream has run this op's leaves AND the main
                     # stream its last reader of these parameters (the data gradient just queued).  The hand-over is parked
