@@ -39,6 +39,16 @@ def test_argument_validation_without_gpu():
     assert L.unetrir_bn_ws_bytes(1024, 64) > 0
     assert L.unetrir_conv2d_wgrad_ws_bytes(C.byref(ConvGeom(32, 256, 256, 64, 64, 3, 1))) > 0
     assert L.unetrir_head6x6_supported(64) == 1 and L.unetrir_head6x6_supported(8) == 1 and L.unetrir_head6x6_supported(20) == 0
+    # deferred split-K reductions: an empty batch is a no-op, a missing descriptor array or a descriptor without buffers is refused
+    from unet_rir_amd._lib import ReduceDesc
+    assert L.unetrir_splitk_reduce_batched(None, 0, None) == 0
+    assert L.unetrir_splitk_reduce_batched(None, 1, None) == 10001
+    d = (ReduceDesc * 2)()
+    assert L.unetrir_splitk_reduce_batched(d, 2, None) == 0               # nsplit == 0: the weight gradient went straight into dw
+    d[1].nsplit = 4
+    assert L.unetrir_splitk_reduce_batched(d, 2, None) == 10001           # slabs to reduce but no buffers
+    g = ConvGeom(1, 8, 8, 8, 8, 3, 1)
+    assert L.unetrir_conv2d_wgrad_partials_bf16(C.byref(g), 16, 8, 16, 8, 16, 0.0, None, 16, 1 << 20, None, None) == 10001      # no descriptor to fill
 
 
 def test_product_has_no_cpu_fallback_and_does_not_import_oracle():
