@@ -1017,6 +1017,30 @@ def test_parked_split_k_reductions_equal_the_immediate_ones_bit_for_bit(U):
     assert len(rb) == 0
     for i, (a, b) in enumerate(zip(got, want)):
         assert torch.equal(a, b), (cases[i], float((a - b).abs().max()))
+    # a descriptor table that fills up before the arena does: the batch flushes itself and goes on
+    rb = ops.ReduceBatch(DEV, 1 << 30, capacity=2)
+    got = []
+    for g, x, dy, w, reg, tr in layers:
+        dw = torch.full_like(w, 7.0)
+        (ops.conv2d_transpose_wgrad if tr else ops.conv2d_wgrad)(g, x, dy, dw, ws, reg=reg, w=w, defer=rb)
+        got.append(dw)
+        assert len(rb) <= 2
+    rb.flush()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), (cases[i], float((a - b).abs().max()))
+    # a threshold on the slab-set size: larger sets reduce at once, smaller ones are parked
+    rb = ops.ReduceBatch(DEV, 1 << 30, park_max_bytes=1 << 20)
+    got = []
+    for g, x, dy, w, reg, tr in layers:
+        dw = torch.full_like(w, 7.0)
+        (ops.conv2d_transpose_wgrad if tr else ops.conv2d_wgrad)(g, x, dy, dw, ws, reg=reg, w=w, defer=rb)
+        got.append(dw)
+    assert 0 < len(rb) < len(cases)
+    rb.flush()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), (cases[i], float((a - b).abs().max()))
     # one big batch too (every layer parked, one flush): an arena that holds them all
     rb = ops.ReduceBatch(DEV, 1 << 30)
     got = []
