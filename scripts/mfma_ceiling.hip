@@ -99,6 +99,125 @@ __global__ __launch_bounds__(512) void loop_kernel(const uint32_t* __restrict__ 
     if (tid == 0) { stamps[blockIdx.x].cyc = __builtin_amdgcn_s_memtime() - c0; stamps[blockIdx.x].real = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
+// ---- loop STRUCTURES (round 4): the same arithmetic per CU and iteration (768 MFMAs of 16x16x32, 192 KB of fragment
+// reads) organised two ways.
+//   barrier8: conv3x3p's shape - 8 waves (two per SIMD), each 24 ds_read_b128 behind the barrier, then 96 MFMAs, one s_barrier per iteration
+//   pipe4:    4 waves (ONE per SIMD, 512 registers each: 64 accumulator tiles), 48 reads per iteration of which the second half is
+//             issued for the NEXT iteration while this iteration's MFMAs run; 192 MFMAs per wave, one s_barrier per iteration
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void struct_kernel(const uint32_t* __restrict__ src, float* __restrict__ sink, int iters, Stamp* stamps) {
+    __shared__ __attribute__((aligned(16))) uint32_t img[16384];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 16384; i += WAVES * 64) img[i] = src[(blockIdx.x * 16384 + i) & 0xFFFFF];
+    __syncthreads();
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)img + lane * 16;
+    uint32_t off = 0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (WAVES == 8) {
+        f32x4 acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 wf[12], pf[12];
+        for (int it = 0; it < iters; ++it) {
+            const uint32_t base = lbase + off;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(base), "n"(i * 1024));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pf[i]) : "v"(base), "n"(12288 + i * 1024));
+            }
+            off = (off + 4096) & 0x7FFF;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int t = 0; t < 32; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[4 * g + (t & 3)]),
+                                                                     __builtin_bit_cast(bf16x8, pf[4 * g + ((t >> 2) & 3)]), acc[t], 0, 0, 0);
+            __builtin_amdgcn_s_barrier();
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sm += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+        if (sm == 123.456f) sink[blockIdx.x * 512 + tid] = sm;
+    } else {
+        f32x4 acc[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 fa[24], fb[24];                 // first / second half of an iteration's 48 fragments
+#pragma unroll
+        for (int i = 0; i < 24; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i]) : "v"(lbase), "n"(i * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // software pipeline: 8 fragment reads for the group that is 96 MFMAs ahead, then 32 MFMAs on fragments that landed long ago
+        // (lgkmcnt is a 4-bit counter: at most the 8 reads just issued are allowed to be outstanding at each wait)
+#define GRP(SRC, DSTACC, G)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                                              \
+    _Pragma("unroll") for (int t = 0; t < 32; ++t)                                                                  \
+        acc[DSTACC + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, SRC[8 * G + (t & 3)]), \
+                                                                  __builtin_bit_cast(bf16x8, SRC[8 * G + 4 + ((t >> 2) & 3)]), acc[DSTACC + t], 0, 0, 0)
+        for (int it = 0; it < iters; ++it) {
+            const uint32_t base = lbase + off + 24576;
+            off = (off + 4096) & 0x3FFF;
+            const uint32_t nbase = lbase + off;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[i]) : "v"(base), "n"(i * 1024));
+            GRP(fa, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[8 + i]) : "v"(base), "n"((8 + i) * 1024));
+            GRP(fa, 0, 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[16 + i]) : "v"(base), "n"((16 + i) * 1024));
+            GRP(fa, 0, 2);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i]) : "v"(nbase), "n"(i * 1024));
+            GRP(fb, 32, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[8 + i]) : "v"(nbase), "n"((8 + i) * 1024));
+            GRP(fb, 32, 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[16 + i]) : "v"(nbase), "n"((16 + i) * 1024));
+            GRP(fb, 32, 2);
+            __builtin_amdgcn_s_barrier();
+        }
+#undef GRP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) sm += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+        if (sm == 123.456f) sink[blockIdx.x * 512 + tid] = sm;
+    }
+    if (tid == 0) { stamps[blockIdx.x].cyc = __builtin_amdgcn_s_memtime() - c0; stamps[blockIdx.x].real = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+
+template <int WAVES>
+static int run_struct(const char* name, const uint32_t* src, float* sink, Stamp* stamps, int cus) {
+    const int iters = 4000;
+    const double flop_per_iter_cu = 768.0 * 16 * 16 * 32 * 2;                 // 8 x 96 = 4 x 192 MFMAs
+    auto t0 = std::chrono::steady_clock::now();
+    while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5) {
+        for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(struct_kernel<WAVES>, dim3(cus), dim3(WAVES * 64), 0, 0, src, sink, iters, stamps);
+        CK(hipDeviceSynchronize());
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 8;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(struct_kernel<WAVES>, dim3(cus), dim3(WAVES * 64), 0, 0, src, sink, iters, stamps);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<Stamp> h(cus);
+    CK(hipMemcpy(h.data(), stamps, sizeof(Stamp) * cus, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (auto& s : h) ghz.push_back((double)s.cyc / (double)s.real * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double tf = flop_per_iter_cu * iters * cus * reps / (ms * 1e-3) / 1e12;
+    const double clk = ghz[ghz.size() / 2];
+    printf("{\"loop\": \"%s\", \"tflops\": %.1f, \"clock_ghz\": %.3f, \"flop_per_cycle_per_cu\": %.0f, \"ms_per_launch\": %.3f, \"frac_of_2500\": %.3f}\n",
+           name, tf, clk, tf * 1e12 / (clk * 1e9) / cus, ms / reps, tf / 2500.0);
+    return 0;
+}
+
 template <int MODE>
 static int run(const char* name, const uint32_t* src, float* sink, Stamp* stamps, int cus) {
     const int iters = 4000;
@@ -149,5 +268,7 @@ int main() {
     if (run<0>("regs_16x16x32", src, sink, stamps, cus)) return 1;
     if (run<1>("lds_16x16x32", src, sink, stamps, cus)) return 1;
     if (run<2>("lds_32x32x16", src, sink, stamps, cus)) return 1;
+    if (run_struct<8>("barrier8: 8 waves, 24 reads behind the barrier, 96 MFMAs, barrier", src, sink, stamps, cus)) return 1;
+    if (run_struct<4>("pipe4: 4 waves (one per SIMD), reads one half-iteration ahead, 192 MFMAs, barrier", src, sink, stamps, cus)) return 1;
     return 0;
 }
