@@ -464,6 +464,46 @@ def test_batchnorm_bf16(U, shape):
     close(cs, gy.sum(dim=(0, 2, 3)), 1e-5, "bf16 colsum")
 
 
+def test_batchnorm_passes_on_a_tensor_past_the_non_temporal_threshold(U):
+    """Tensors of 100 MB and more take the non-temporal-load instances of the three BatchNorm passes (csrc/elementwise.hip: bn_nt) -
+    the full-resolution levels of BASELINE.json configs[1].  [8, 256, 256, 128] bf16 = 134 MB: (1) the forward apply equals the apply of
+    its two 67 MB halves (plain instances) bit for bit; (2) statistics, backward sums and dx against the same arithmetic in fp64."""
+    ops = U.ops
+    B, H, W, Cc = 8, 256, 256, 128
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    x = (torch.rand((B, H, W, Cc), device=DEV, generator=g) * 4 - 2).to(torch.bfloat16)
+    gy = (torch.rand((B, H, W, Cc), device=DEV, generator=g) * 2 - 1).to(torch.bfloat16)
+    assert x.numel() * 2 >= 100 << 20 and x[:B // 2].numel() * 2 < 100 << 20
+    gamma = torch.rand(Cc, device=DEV, generator=g) + 0.5
+    beta = torch.rand(Cc, device=DEV, generator=g) - 0.5
+    ws = ops.Workspace(DEV)
+    xa, gya = ops.Act(x), ops.Act(gy)
+    aff = torch.empty(2 * Cc, device=DEV); saved = torch.empty(2 * Cc, device=DEV)
+    ops.bn_stats(xa, gamma, beta, aff, saved, ws)
+    ya = ops.Act(torch.empty_like(x))
+    ops.bn_apply(xa, aff, ya, relu=True)
+    halves = torch.empty_like(x)
+    for h in range(2):
+        sl = slice(h * B // 2, (h + 1) * B // 2)
+        ops.bn_apply(ops.Act(x[sl]), aff, ops.Act(halves[sl]), relu=True)
+    dxa = ops.Act(torch.empty_like(x))
+    dg = torch.empty(Cc, device=DEV); db = torch.empty(Cc, device=DEV)
+    ops.bn_bwd(gya, xa, gamma, aff, saved, dxa, dg, db, ws, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ya.dense(), halves)
+    x64, g64 = x.double(), gy.double()
+    mu = x64.mean(dim=(0, 1, 2)); var = x64.var(dim=(0, 1, 2), unbiased=False)
+    rs = 1.0 / torch.sqrt(var + 1e-3)
+    close(saved[:Cc], mu, 1e-6, "mean"); close(saved[Cc:], rs, 1e-6, "rstd")
+    xh = (x64 - mu) * rs
+    y64 = torch.relu(xh * gamma.double() + beta.double())
+    close(ya.dense(), y64, 1e-2, "apply")
+    gm = g64 * (ya.dense() > 0)             # the forward pass's own ReLU decisions (an fp64 mask flips where x * scale + shift rounds to 0)
+    close(db, gm.sum(dim=(0, 1, 2)), 1e-5, "dbeta"); close(dg, (gm * xh).sum(dim=(0, 1, 2)), 1e-5, "dgamma")
+    dx64 = gamma.double() * rs * (gm - gm.mean(dim=(0, 1, 2)) - xh * (gm * xh).mean(dim=(0, 1, 2)))
+    close(dxa.dense(), dx64, 1e-2, "dx")
+
+
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 20, 37, 32), (1, 70, 200, 64), (1, 33, 256, 128), (1, 12, 300, 64), (2, 9, 20, 16),
                                       (1, 19, 512, 128), (2, 35, 523, 64), (1, 7, 257, 32)])
 def test_head_and_loss_bf16(U, B, H, W, Cc):

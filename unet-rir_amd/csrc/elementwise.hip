@@ -47,6 +47,22 @@ __device__ __forceinline__ void stv(__bf16* p, const float (&o)[8]) {
     *reinterpret_cast<bf16x8_t*>(p) = v;
 }
 
+// Loads of the BatchNorm passes.  NT: non-temporal - for tensors larger than the Infinity Cache (the full-resolution levels of configs[1]:
+// 268 MB each), which a pass reads once: the lines it would displace are the ones the NEXT kernel reads (round 4: - 0.2 ms per step at
+// configs[1]; on the <= 134 MB tensors of configs[4] the same policy costs 0.1 ms, so the launch chooses by size - bn_nt()).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void ldv_s(const float* p, float (&o)[4]) {
+    const f32x4_t* q = reinterpret_cast<const f32x4_t*>(p);
+    const f32x4_t v = NT ? __builtin_nontemporal_load(q) : *q;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+template <bool NT> __device__ __forceinline__ void ldv_s(const __bf16* p, float (&o)[8]) {
+    const bf16x8_t* q = reinterpret_cast<const bf16x8_t*>(p);
+    const bf16x8_t v = NT ? __builtin_nontemporal_load(q) : *q;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+}
+
 namespace {
 
 struct ChanPlan { int QB, RB, ngroups, nslab; long long rows_per_slab; };
@@ -79,7 +95,7 @@ inline ChanPlan chan_plan(long long P, int C, int vec = 4) {
 //                                               MODE 2: (sum g, sum g*xhat) with g = da*[relu mask]
 // partial layout: double part[nslab][C][2]
 // -------------------------------------------------------------------------------------------
-template <int MODE, typename T>
+template <int MODE, typename T, bool NT = false>
 __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__ x, int ldx,
                                                            const T* __restrict__ da, int ldda,
                                                            const float* __restrict__ affine,
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
     if (cok) {
         for (long long p = p0 + rl; p < p1; p += pstep) {
             float xv[V];
-            ldv(x + (size_t)p * ldx + c0, xv);
+            ldv_s<NT>(x + (size_t)p * ldx + c0, xv);
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) { const double d = xv[k]; s0[k] += d; s1[k] += d * d; }
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
                 for (int k = 0; k < V; ++k) s0[k] += (double)xv[k];
             } else {
                 float gv[V], mv[V];
-                ldv(da + (size_t)p * ldda + c0, gv);
-                if (msk) ldv(msk + (size_t)p * ldm + c0, mv);
+                ldv_s<NT>(da + (size_t)p * ldda + c0, gv);
+                if (msk) ldv_s<NT>(msk + (size_t)p * ldm + c0, mv);
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
                     const float a = msk ? mv[k] : xv[k] * sc[k] + sh[k];
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(const double* __
 // y = x*scale + shift (ReLU optional), one 16-byte vector per lane over [P][C].  The grid stride is a multiple of the
 // channel-vector count whenever C/V divides the 256-thread block (every layer here), so a thread keeps ONE channel group
 // and its per-channel parameters live in registers for the whole loop instead of being re-fetched per element.
-template <typename T>
+template <typename T, bool NT = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long P, int C,
                                                        const float* __restrict__ affine, int relu,
                                                        T* __restrict__ y, int ldy,
@@ -278,12 +294,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         const long long pstep = stride / CQ;
         for (long long p = i0 / CQ; p < P; p += pstep) {
             float r[V];
-            ldv(x + (size_t)p * ldx + c0, r);
+            ldv_s<NT>(x + (size_t)p * ldx + c0, r);
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] = r[k] * sc[k] + sh[k];
             if (addend) {     // Add() in front of the activation (residual blocks, dl_models/res_ae.py:334, :478)
                 float ad[V];
-                ldv(addend + (size_t)p * ldadd + c0, ad);
+                ldv_s<NT>(addend + (size_t)p * ldadd + c0, ad);
 #pragma unroll
                 for (int k = 0; k < V; ++k) r[k] += ad[k];
             }
@@ -299,14 +315,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         const long long p = i / CQ;
         const int c0 = (int)(i - p * CQ) * V;
         float r[V];
-        ldv(x + (size_t)p * ldx + c0, r);
+        ldv_s<NT>(x + (size_t)p * ldx + c0, r);
         if (affine) {
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] = r[k] * affine[c0 + k] + affine[C + c0 + k];
         }
         if (addend) {
             float ad[V];
-            ldv(addend + (size_t)p * ldadd + c0, ad);
+            ldv_s<NT>(addend + (size_t)p * ldadd + c0, ad);
 #pragma unroll
             for (int k = 0; k < V; ++k) r[k] += ad[k];
         }
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // dx = scale * (g - mean(g) - xhat * mean(g*xhat)),  g = da * relu-mask;  without BN (affine == NULL): dx = g
-template <typename T>
+template <typename T, bool NT = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, int ldda,
                                                            const T* __restrict__ x, int ldx, long long P, int C,
                                                            const float* __restrict__ affine,
@@ -352,9 +368,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 for (int k = 0; k < V; ++k) { sc[k] = affine[cc + k]; mu[k] = saved[cc + k]; rs[k] = saved[C + cc + k]; c1[k] = coef[cc + k]; c2[k] = coef[C + cc + k]; }
             }
             float xv[V], gv[V], mv[V], out[V], go[V];
-            ldv(x + (size_t)p * ldx + cc, xv);
-            ldv(da + (size_t)p * ldda + cc, gv);
-            ldv(msk + (size_t)p * ldm + cc, mv);
+            ldv_s<NT>(x + (size_t)p * ldx + cc, xv);
+            ldv_s<NT>(da + (size_t)p * ldda + cc, gv);
+            ldv_s<NT>(msk + (size_t)p * ldm + cc, mv);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float g = (relu && !(mv[k] > 0.f)) ? (relu == 2 ? 0.3f * gv[k] : 0.f) : gv[k];
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (g2) {
                 if (g2add) {
                     float ad[V];
-                    ldv(g2add + (size_t)p * ldg2a + cc, ad);
+                    ldv_s<NT>(g2add + (size_t)p * ldg2a + cc, ad);
 #pragma unroll
                     for (int k = 0; k < V; ++k) go[k] += ad[k];
                 }
@@ -386,8 +402,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const long long pstep = stride / CQ;
         for (long long p = i0 / CQ; p < P; p += pstep) {
             float xv[V], gv[V], out[V];
-            ldv(x + (size_t)p * ldx + c0, xv);
-            ldv(da + (size_t)p * ldda + c0, gv);
+            ldv_s<NT>(x + (size_t)p * ldx + c0, xv);
+            ldv_s<NT>(da + (size_t)p * ldda + c0, gv);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float a = xv[k] * sc[k] + sh[k];
@@ -403,8 +419,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const long long p = i / CQ;
         const int c0 = (int)(i - p * CQ) * V;
         float xv[V], gv[V], out[V];
-        ldv(x + (size_t)p * ldx + c0, xv);
-        ldv(da + (size_t)p * ldda + c0, gv);
+        ldv_s<NT>(x + (size_t)p * ldx + c0, xv);
+        ldv_s<NT>(da + (size_t)p * ldda + c0, gv);
         if (affine) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -706,6 +722,24 @@ static inline unsigned grid_for(long long n, int per_block = 256, int cap = 4096
 }
 static inline unsigned chan_pad_lds() { return 0u; }
 static inline int bn_nohoist_flag() { return 0; }
+#ifndef UNETRIR_BN_NT_MIN_MB
+#define UNETRIR_BN_NT_MIN_MB 100
+#endif
+// non-temporal loads for a BatchNorm pass over a tensor of this many bytes (see ldv_s)
+static inline bool bn_nt(long long P, int C, size_t elem) { return P * C * (long long)elem >= ((long long)UNETRIR_BN_NT_MIN_MB << 20); }
+// launches with NT chosen at run time
+template <int MODE, typename T, typename... A> static inline void launch_chan_partial(bool nt, dim3 grid, hipStream_t s, A... a) {
+    if (nt) hipLaunchKernelGGL((chan_partial_kernel<MODE, T, true>), grid, dim3(256), 0, s, a...);
+    else hipLaunchKernelGGL((chan_partial_kernel<MODE, T, false>), grid, dim3(256), 0, s, a...);
+}
+template <typename T, typename... A> static inline void launch_bn_apply(bool nt, dim3 grid, hipStream_t s, A... a) {
+    if (nt) hipLaunchKernelGGL((bn_apply_kernel<T, true>), grid, dim3(256), 0, s, a...);
+    else hipLaunchKernelGGL((bn_apply_kernel<T, false>), grid, dim3(256), 0, s, a...);
+}
+template <typename T, typename... A> static inline void launch_bn_bwd_apply(bool nt, dim3 grid, hipStream_t s, A... a) {
+    if (nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), grid, dim3(256), 0, s, a...);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), grid, dim3(256), 0, s, a...);
+}
 static inline bool chan_ok(const void* x, int ld, long long P, int C, int vec = 4) {
     return x && P > 0 && C > 0 && C % vec == 0 && ld >= C && ld % vec == 0 && ((uintptr_t)x & 15) == 0;
 }
@@ -717,7 +751,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
                   float* moving_mean, float* moving_var, float* affine, float* saved, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !affine || !saved || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
-    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, (const T*)nullptr, 0,
+    launch_chan_partial<0, T>(bn_nt(P, C, sizeof(T)), dim3(pl.nslab, pl.ngroups), s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
     hipLaunchKernelGGL(bn_finalize_kernel<double>, fin_grid(C), dim3(FIN_T), 0, s, (const double*)ws, pl.nslab, P, C, gamma,
                        beta, eps, momentum, moving_mean, moving_var, affine, saved);
@@ -727,7 +761,7 @@ int bn_stats_impl(const T* x, int ldx, long long P, int C, const float* gamma, c
 template <typename T>
 int bn_apply_impl(const T* x, int ldx, long long P, int C, const float* affine, int relu, T* y, int ldy, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !y || ldy < C || ldy % VecOf<T>::N) return UNETRIR_EINVAL;
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, x, ldx, P, C, affine, relu | bn_nohoist_flag(), y, ldy);
+    launch_bn_apply<T>(bn_nt(P, C, sizeof(T)), dim3(grid_for(P * (C / VecOf<T>::N))), s, x, ldx, P, C, affine, relu | bn_nohoist_flag(), y, ldy);
     return (int)hipGetLastError();
 }
 
@@ -740,10 +774,10 @@ int bn_bwd_impl(const T* da, int ldda, const T* x, int ldx, long long P, int C, 
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
-    hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, da, ldda, affine, saved,
+    launch_chan_partial<2, T>(bn_nt(P, C, sizeof(T)), dim3(pl.nslab, pl.ngroups), s, x, ldx, da, ldda, affine, saved,
                        relu, P, C, pl.QB, pl.rows_per_slab, part);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, fin_grid(C), dim3(FIN_T), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / VecOf<T>::N))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
+    launch_bn_bwd_apply<T>(bn_nt(P, C, sizeof(T)), dim3(grid_for(P * (C / VecOf<T>::N))), s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, relu | bn_nohoist_flag(), dx, lddx);
     return (int)hipGetLastError();
 }
@@ -761,10 +795,10 @@ int bn_bwd_junction_impl(const T* da, int ldda, const T* x, int ldx, const T* ou
     const ChanPlan pl = chan_plan(P, C, V);
     double* part = (double*)ws;
     float* coef = (float*)(part + (size_t)pl.nslab * C * 2);
-    hipLaunchKernelGGL((chan_partial_kernel<2, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, da, ldda, affine, saved,
+    launch_chan_partial<2, T>(bn_nt(P, C, sizeof(T)), dim3(pl.nslab, pl.ngroups), s, x, ldx, da, ldda, affine, saved,
                        act, P, C, pl.QB, pl.rows_per_slab, part, out, ldo);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, fin_grid(C), dim3(FIN_T), 0, s, (const double*)part, pl.nslab, P, C, dgamma, dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, da, ldda, x, ldx, P, C, affine, saved,
+    launch_bn_bwd_apply<T>(bn_nt(P, C, sizeof(T)), dim3(grid_for(P * (C / V))), s, da, ldda, x, ldx, P, C, affine, saved,
                        (const float*)coef, act, dx, lddx, out, ldo, gskip, ldgs, gskip_add, ldga);
     return (int)hipGetLastError();
 }
@@ -773,7 +807,7 @@ template <typename T>
 int colsum_impl(const T* x, int ldx, long long P, int C, float* out, void* ws, size_t ws_bytes, hipStream_t s) {
     if (!chan_ok(x, ldx, P, C, VecOf<T>::N) || !out || !ws || ws_bytes < unetrir_bn_ws_bytes(P, C)) return UNETRIR_EINVAL;
     const ChanPlan pl = chan_plan(P, C, VecOf<T>::N);
-    hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3(pl.nslab, pl.ngroups), dim3(256), chan_pad_lds(), s, x, ldx, (const T*)nullptr, 0,
+    launch_chan_partial<1, T>(bn_nt(P, C, sizeof(T)), dim3(pl.nslab, pl.ngroups), s, x, ldx, (const T*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, 0, P, C, pl.QB, pl.rows_per_slab, (double*)ws);
     hipLaunchKernelGGL(colsum_finalize_kernel<double>, fin_grid(C), dim3(FIN_T), 0, s, (const double*)ws, pl.nslab, C, out, 0, C);
     return (int)hipGetLastError();
@@ -1135,7 +1169,7 @@ static int bn_colstat_act_add_impl(const float* colstat, long long rows, const T
         act > 2 || (addend && (ldadd < C || ldadd % V)))
         return UNETRIR_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel<float>, fin_grid(C), dim3(FIN_T), 0, s, colstat, (int)rows, P, C, gamma, beta, eps, momentum, mm, mv, affine, saved);
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(P * (C / V))), dim3(256), 0, s, x, ldx, P, C, (const float*)affine, act, y, ldy, addend, ldadd);
+    launch_bn_apply<T>(bn_nt(P, C, sizeof(T)), dim3(grid_for(P * (C / V))), s, x, ldx, P, C, (const float*)affine, act, y, ldy, addend, ldadd);
     return (int)hipGetLastError();
 }
 
