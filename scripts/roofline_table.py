@@ -134,13 +134,18 @@ def main():
             kn = serving_kernel(L, ConvGeom, name, cin, cout, h, k, s, tr, what)
             gf, by = work(cin, cout, h, k, s, tr, what)
             served.setdefault(kn, []).append((name, what, gf, by))
-    # BatchNormalization passes: 13 layers, bf16 tensors [B, h, h, c]: apply = 1 read + 1 write, backward reduce = 2 reads, backward apply = 2 reads + 1 write
+    # BatchNormalization passes: 13 layers, bf16 tensors [B, h, h, c]: apply = 1 read + 1 write, backward reduce = 2 reads, backward apply = 2 reads + 1 write.
+    # Tensors of 100 MB and more run the non-temporal-load instances (csrc/elementwise.hip bn_nt); rocprofv3 prints those instances with a
+    # garbled demangling ("<bool _Accum, bool, E>": its demangler does not know the __bf16 mangling DF16b) and the plain ones mangled.
     bn = []
     for name, cin, cout, h, k, s, tr in layers():
         if ".cb1" in name:
             bn.append(2.0 * B * h * h * cout)
-    for kn, passes in (("_Z15bn_apply_kernelIDF16b", 2), ("_Z19chan_partial_kernelILi2EDF16b", 2), ("_Z19bn_bwd_apply_kernelIDF16b", 3)):
-        served[kn] = [("BatchNorm layer", "pass", 0.0, passes * t) for t in bn]
+    big, small = [t for t in bn if t >= 100 << 20], [t for t in bn if t < 100 << 20]
+    for kn_nt, kn, passes in (("bn_apply_kernel<bool _Accum", "_Z15bn_apply_kernelIDF16b", 2), ("chan_partial_kernel<2, bool _Accum", "_Z19chan_partial_kernelILi2EDF16b", 2),
+                              ("bn_bwd_apply_kernel<bool _Accum", "_Z19bn_bwd_apply_kernelIDF16b", 3)):
+        served[kn_nt] = [("BatchNorm layer >= 100 MB (non-temporal loads)", "pass", 0.0, passes * t) for t in big]
+        served[kn] = [("BatchNorm layer < 100 MB", "pass", 0.0, passes * t) for t in small]
     served["adam_kernel"] = [("all parameters", "optimizer", 0.0, 28.0 * 68_613_058)]
     fetch, write, mf = parse_pmc(fetch_p, "FETCH_SIZE"), parse_pmc(write_p, "WRITE_SIZE"), parse_mfma(mfma_p)
     table, total_ms = {}, 0.0
