@@ -268,3 +268,71 @@ def test_save_load_round_trip(env, tmp_path):
     b = again.predict_stft(x)
     env.sync()
     assert torch.equal(a, b)
+
+
+def test_compile_and_fit_follows_the_keras_recipe_of_the_reference(env, tmp_path, monkeypatch):
+    """dl_models/u_net.py:72-118: compile(Adam(InverseTimeDecay(lr, steps_per_epoch * 100, 1)), MSE) + fit(batch_size, epochs,
+    shuffle=False, [CSVLogger(name.log), EarlyStopping(val_loss, 20)]).  Against the same recipe written on the oracle in fp64: per-epoch
+    `loss` (batch-size weighted mean of MSE + l2 terms, training-mode BatchNorm) and `val_loss` (moving statistics), a last batch smaller
+    than batch_size, the rate decaying with the optimizer's step count; the CSV log holds the history."""
+    import math
+    monkeypatch.chdir(tmp_path)
+    cfg = R.Config(H, W, F0, 3)
+    n_train, n_val, bs, epochs, spe, lr0 = 6, 3, 4, 3, 2, 1e-3
+    spec_in, emb, spec_out = R.synthetic_batch(cfg, n_train, seed_name="fit")
+    v_in, v_emb, v_out = R.synthetic_batch(cfg, n_val, seed_name="fitval")
+    model = env.unet(bs, dropout=False, learning_rate=lr0, name="fit-test")
+    params = _load(model, cfg)
+    nhwc = lambda a: np.ascontiguousarray(np.transpose(np.asarray(a), (0, 2, 3, 1)))
+    hist = model.compile_and_fit(nhwc(spec_in), emb, nhwc(spec_out), nhwc(v_in), v_emb, nhwc(v_out), bs, epochs, spe)
+    env.sync()
+    # the oracle's trajectory
+    st = R.TrainState(cfg, params, dtype=torch.float64)
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    want, it = {"loss": [], "val_loss": []}, 0
+    for _ in range(epochs):
+        tot = 0.0
+        for i in range(0, n_train, bs):
+            sl = slice(i, min(i + bs, n_train))
+            for p in st.P.values():
+                p.grad = None
+            pred = R.forward(st.P, t64(spec_in[sl]), torch.tensor(emb[sl]), cfg, True, None, st.bn_state)
+            loss = ((pred - t64(spec_out[sl])) ** 2).mean() + R.reg_loss(st.P, cfg, 1)
+            loss.backward()
+            st.t += 1
+            with torch.no_grad():
+                for k, p in st.P.items():
+                    g = p.grad if p.grad is not None else torch.zeros_like(p)
+                    new, st.m[k], st.v[k] = R.adam_update(p, g, st.m[k], st.v[k], st.t, lr0 / (1.0 + it / (spe * 100.0)))
+                    p.copy_(new)
+            it += 1
+            tot += float(loss) * (sl.stop - sl.start)
+        want["loss"].append(tot / n_train)
+        with torch.no_grad():
+            pred = R.forward(st.P, t64(v_in), torch.tensor(v_emb), cfg, False, None, st.bn_state)
+            want["val_loss"].append(float(((pred - t64(v_out)) ** 2).mean() + R.reg_loss(st.P, cfg, 1)))
+    assert set(hist) == {"loss", "val_loss"} and len(hist["loss"]) == len(hist["val_loss"]) == epochs
+    for k in want:
+        for a, b in zip(hist[k], want[k]):
+            assert math.isfinite(a) and abs(a - b) <= 2e-4 * abs(b), (k, hist[k], want[k])
+    assert hist["loss"][-1] < hist["loss"][0]
+    rows = (tmp_path / "fit-test.log").read_text().strip().splitlines()
+    assert rows[0] == "epoch,loss,val_loss" and len(rows) == 1 + epochs and rows[1].startswith("0,")
+    assert abs(float(rows[-1].split(",")[1]) - hist["loss"][-1]) <= 1e-12
+
+
+def test_early_stopping_and_csv_logger_callbacks():
+    """Keras' EarlyStopping(monitor='val_loss', patience) semantics: stop after `patience` epochs without a new minimum."""
+    from unet_rir_amd import callbacks
+
+    class M:
+        stop_training = False
+    m, cb = M(), callbacks.EarlyStopping(monitor="val_loss", patience=3)
+    cb.set_model(m)
+    cb.on_train_begin()
+    seq = [1.0, 0.9, 0.95, 0.91, 0.9, 0.7]
+    for e, v in enumerate(seq):
+        cb.on_epoch_end(e, {"val_loss": v, "loss": 0.0})
+        if m.stop_training:
+            break
+    assert e == 4 and cb.stopped_epoch == 4 and cb.best == 0.9 and cb.best_epoch == 1       # 0.9 again is not an improvement

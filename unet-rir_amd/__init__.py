@@ -3,7 +3,7 @@
 Host side in Python over a C ABI (include/unetrir.h) of hand-written HIP kernels; PyTorch provides
 device memory, streams and torch.distributed only.
 """
-from . import _lib, build, ops  # noqa: F401
+from . import _lib, build, callbacks, ops  # noqa: F401
 from ._lib import UnetrirError  # noqa: F401
 from .engine import UNetEngine  # noqa: F401
 from .device import HipRuntime  # noqa: F401

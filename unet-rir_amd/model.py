@@ -208,6 +208,81 @@ class _EngineModule(nn.Module):
             return _ModelFunction.apply(self, eng, self._anchor, spec, emb, dropout_mask, *extra)
         return eng.forward(spec, emb, dropout_mask=dropout_mask)
 
+    # ---- dl_models/u_net.py:72-118 (the same two methods in res_ae.py:78-127 and autoencoder.py:72-121)
+    def get_callbacks(self):
+        """CSVLogger(f'{name}.log') + EarlyStopping(monitor='val_loss', patience=20), dl_models/u_net.py:72-81."""
+        from . import callbacks
+        return [callbacks.CSVLogger(f"{self.name}.log", separator=",", append=False),
+                callbacks.EarlyStopping(monitor="val_loss", patience=20)]
+
+    def compile_and_fit(self, x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch):
+        """dl_models/u_net.py:83-118: `model.compile(Adam(InverseTimeDecay(learning_rate, decay_steps=steps_per_epoch * 100, decay_rate=1)),
+        loss=MeanSquaredError())` + `model.fit(x=[x_train1, x_train2], y=y_train, validation_data=..., batch_size, epochs, shuffle=False,
+        callbacks=get_callbacks())`; returns `History.history` ({'loss': [...], 'val_loss': [...]}).
+
+        Spectrograms are the reference's NHWC arrays [N, H, W, 2] (numpy or torch), information vectors [N, 2, 16] integers.  As in Keras
+        the reported losses are the batch-size weighted means over an epoch of MSE + the l2 terms of `model.losses`, the validation pass
+        runs on the moving BatchNorm statistics without Dropout, and the optimizer is the engine's Keras-Adam kernel (epsilon 1e-7
+        outside the root) at the rate the schedule gives for the number of steps already taken."""
+        lr0, decay_steps = float(self.learning_rate), float(steps_per_epoch * 100)
+        self.summary()
+        cbs = self.get_callbacks()
+        self.stop_training = False
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin()
+        history = {"loss": [], "val_loss": []}
+
+        def batches(x1, x2, y):
+            n = len(x1)
+            for i in range(0, n, batch_size):
+                sl = slice(i, min(i + batch_size, n))
+                spec = torch.as_tensor(x1[sl]).to(self._device, torch.float32).permute(0, 3, 1, 2).contiguous()
+                tgt = torch.as_tensor(y[sl]).to(self._device, torch.float32).permute(0, 3, 1, 2).contiguous()
+                yield spec, torch.as_tensor(x2[sl]).to(self._device), tgt
+
+        def total_loss(pred, tgt):
+            return ((pred - tgt) ** 2).mean() + sum(self.regularization_losses())
+
+        iterations = 0
+        for epoch in range(num_epochs):
+            self.train()
+            tot, cnt = 0.0, 0
+            for spec, emb, tgt in batches(x_train1, x_train2, y_train):
+                for p in self._params:
+                    p.grad = None
+                loss = total_loss(self(spec, emb), tgt)
+                loss.backward()
+                eng = self._engine_for(spec.shape[0])
+                if not self.fold_l2:                      # gradients arrived as autograd tensors: hand them to the engine's buffer
+                    for n, p in zip(self._param_names, self._params):
+                        eng.g[n].copy_(p.grad if p.grad is not None else torch.zeros_like(p))
+                eng.adam_step(lr0 / (1.0 + iterations / decay_steps))
+                eng.t_dirty = True
+                iterations += 1
+                tot += float(loss.detach()) * spec.shape[0]
+                cnt += spec.shape[0]
+            logs = {"loss": tot / max(cnt, 1)}
+            self.eval()
+            tot, cnt = 0.0, 0
+            with torch.no_grad():
+                for spec, emb, tgt in batches(x_val1, x_val2, y_val):
+                    tot += float(total_loss(self(spec, emb), tgt)) * spec.shape[0]
+                    cnt += spec.shape[0]
+            if cnt:
+                logs["val_loss"] = tot / cnt
+            for k, v in logs.items():
+                history[k].append(v)
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
+                break
+        for cb in cbs:
+            cb.on_train_end()
+        if not history["val_loss"]:
+            del history["val_loss"]
+        return history
+
     def predict_stft(self, inputs):
         """dl_models/u_net.py:138-146: model.predict([spectrograms NHWC, vectors]) -> generated spectrograms NHWC."""
         return self.model.predict(inputs)
