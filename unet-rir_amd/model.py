@@ -215,8 +215,9 @@ class _EngineModule(nn.Module):
         return [callbacks.CSVLogger(f"{self.name}.log", separator=",", append=False),
                 callbacks.EarlyStopping(monitor="val_loss", patience=20)]
 
-    def compile_and_fit(self, x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch):
-        """dl_models/u_net.py:83-118: `model.compile(Adam(InverseTimeDecay(learning_rate, decay_steps=steps_per_epoch * 100, decay_rate=1)),
+    def _compile_and_fit(self, x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch, learning_rate):
+        """dl_models/u_net.py:83-118 (UNet: the rate is the constructor's; res_ae.py:89-127, autoencoder.py:83-121: an argument,
+        default 1e-5): `model.compile(Adam(InverseTimeDecay(learning_rate, decay_steps=steps_per_epoch * 100, decay_rate=1)),
         loss=MeanSquaredError())` + `model.fit(x=[x_train1, x_train2], y=y_train, validation_data=..., batch_size, epochs, shuffle=False,
         callbacks=get_callbacks())`; returns `History.history` ({'loss': [...], 'val_loss': [...]}).
 
@@ -224,7 +225,7 @@ class _EngineModule(nn.Module):
         the reported losses are the batch-size weighted means over an epoch of MSE + the l2 terms of `model.losses`, the validation pass
         runs on the moving BatchNorm statistics without Dropout, and the optimizer is the engine's Keras-Adam kernel (epsilon 1e-7
         outside the root) at the rate the schedule gives for the number of steps already taken."""
-        lr0, decay_steps = float(self.learning_rate), float(steps_per_epoch * 100)
+        lr0, decay_steps = float(learning_rate), float(steps_per_epoch * 100)
         self.summary()
         cbs = self.get_callbacks()
         self.stop_training = False
@@ -346,6 +347,11 @@ class UNet(_EngineModule):
         self.dtype_name, self.overlap = dtype, overlap
         self._finish_init()
 
+    def compile_and_fit(self, x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch):
+        """dl_models/u_net.py:83-118 (signature as there: the rate is the constructor's `learning_rate`)."""
+        return self._compile_and_fit(x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch,
+                                     self.learning_rate)
+
     def _new_engine(self, B, share):
         if self.mode == 0:
             return UNetEngine(self.H, self.W, B, F0=self.number_filters_0, k=self.kernels, depth=self.depth,
@@ -428,6 +434,12 @@ class _AEFamily(_EngineModule):
         return self.ENGINE(self.H, self.W, B, self.conv_filters, self.conv_kernels, self.conv_strides, self.latent_space_dim,
                            self.n_neurons, self.inf_vector_shape, device=self._device, n_replicas=self.n_replicas,
                            runtime=self._rt, share=share, dtype=self.dtype_name, overlap_wgrad=self.overlap)
+
+    def compile_and_fit(self, x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch,
+                        learning_rate=0.00001):
+        """dl_models/res_ae.py:89-127, dl_models/autoencoder.py:83-121 (signature as there)."""
+        return self._compile_and_fit(x_train1, x_train2, y_train, x_val1, x_val2, y_val, batch_size, num_epochs, steps_per_epoch,
+                                     learning_rate)
 
     @property
     def encoder(self):
