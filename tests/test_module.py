@@ -345,18 +345,18 @@ def test_compile_and_fit_on_the_residual_autoencoder_class(env, tmp_path, monkey
     import math
     monkeypatch.chdir(tmp_path)
     cfg = RA.ResAEConfig(H, W, (8, 8, 8, 16), (3, 3, 3, 3), (2, 2, 2, 2), 8, 16)
-    spec_in, emb, spec_out = R.synthetic_batch(R.Config(H, W), 5, seed_name="rfit")
+    spec_in, emb, spec_out = R.synthetic_batch(R.Config(H, W), 3, seed_name="rfit")
     model = env.U.ResAE((H, W, 2), (2, 16), cfg.conv_filters, cfg.conv_kernels, cfg.conv_strides, cfg.latent_space_dim,
                         cfg.n_neurons, name="resae-fit", batch_size=2, device=env.device, runtime=env.rt, dropout=False)
     model.engine.load_keras_params(RA.init_params(cfg, randomize_all=True, dtype=np.float64))
     nhwc = lambda a: np.ascontiguousarray(np.transpose(np.asarray(a), (0, 2, 3, 1)))
-    hist = model.compile_and_fit(nhwc(spec_in), emb, nhwc(spec_out), nhwc(spec_in[:2]), emb[:2], nhwc(spec_out[:2]), 2, 4, 3, learning_rate=2e-3)
+    hist = model.compile_and_fit(nhwc(spec_in), emb, nhwc(spec_out), nhwc(spec_in[:2]), emb[:2], nhwc(spec_out[:2]), 2, 3, 2, learning_rate=2e-3)
     env.sync()
-    assert len(hist["loss"]) == len(hist["val_loss"]) == 4 and all(math.isfinite(v) for v in hist["loss"] + hist["val_loss"])
+    assert len(hist["loss"]) == len(hist["val_loss"]) == 3 and all(math.isfinite(v) for v in hist["loss"] + hist["val_loss"])
     assert hist["loss"][-1] < hist["loss"][0]
-    assert len((tmp_path / "resae-fit.log").read_text().strip().splitlines()) == 5
+    assert len((tmp_path / "resae-fit.log").read_text().strip().splitlines()) == 4
     # patience 1 on a loss that cannot improve (rate 0): Keras stops at the end of the second epoch
     from unet_rir_amd import callbacks
     model.get_callbacks = lambda: [callbacks.EarlyStopping(monitor="loss", patience=1)]
-    hist = model.compile_and_fit(nhwc(spec_in), emb, nhwc(spec_out), nhwc(spec_in[:2]), emb[:2], nhwc(spec_out[:2]), 2, 6, 3, learning_rate=0.0)
+    hist = model.compile_and_fit(nhwc(spec_in), emb, nhwc(spec_out), nhwc(spec_in[:2]), emb[:2], nhwc(spec_out[:2]), 2, 4, 2, learning_rate=0.0)
     assert len(hist["loss"]) == 2
